@@ -1,0 +1,158 @@
+/*
+ * mgx — C ABI of the MI355X (gfx950) implementation of the V-cycle level
+ * operators of zerothi/multigrid.
+ *
+ * The reference has no FFI for this path: its level operators are Fortran
+ * module procedures on type(mg_grid) (src/t_mg.f90:22-60).  This header
+ * declares the boundary a Fortran host binds with ISO_C_BINDING (or any other
+ * host with ctypes/cgo/...) at the seam between the reference's cycle control
+ * (src/m_gs_CDS.F90:21-294, stays on the host) and its level operators
+ * (replaced by HIP kernels).  Each entry point names the reference routine
+ * whose call sites it replaces.
+ *
+ * Conventions
+ *  - every function returns 0 on success, a negative MGX_E* code otherwise;
+ *    mgx_last_error() gives a message for the calling thread.  A Fortran shim
+ *    turns non-zero into `stop 'msg'` like the reference (t_mg.f90:135,334).
+ *  - handles are opaque; device memory is owned by the library; host arrays
+ *    are only borrowed during upload/download.
+ *  - host-side fields use the reference layout V(0:n1+1,0:n2+1,0:n3+1),
+ *    column major, element type real(4) (elem_bytes 4) or real(8) (8).
+ *  - one host thread drives a context; work is enqueued on the context's HIP
+ *    stream and only the calls marked [sync] wait for it.
+ *  - box tables follow t_mg.f90:62-72: place = xmin,xmax,ymin,ymax,zmin,zmax
+ *    (1-based, inclusive; Fortran place(2,3) in memory order), unused slots
+ *    have place = 0 and still take part in mgx_level_tolerance.
+ */
+#ifndef MGX_H
+#define MGX_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef struct mgx_ctx mgx_ctx;
+typedef struct mgx_level mgx_level;
+
+enum {
+  MGX_OK = 0,
+  MGX_EINVAL = -1,   /* bad argument (message says which) */
+  MGX_EHIP = -2,     /* a HIP runtime call failed */
+  MGX_ENOMEM = -3,   /* device allocation failed */
+  MGX_ESTATE = -4,   /* call not valid in the level's current state */
+  MGX_ELIMIT = -5    /* size beyond a documented limit */
+};
+
+/* boundary-condition codes, src/t_bc.f90:13-15 */
+enum { MGX_BC_PERIODIC = 1, MGX_BC_DIRICHLET = 2, MGX_BC_NEUMANN = 3 };
+/* transfer-operator codes, src/t_mg.f90:19-20 */
+enum { MGX_INTERP_FULL = 1, MGX_INTERP_HALF = 2 };
+/* which reductions a sweep accumulates */
+enum { MGX_RED_ERR = 1, MGX_RED_SUM = 2 };
+/* sweep kernel selection (results are bit-identical; for benchmarking) */
+enum { MGX_KERNEL_AUTO = 0, MGX_KERNEL_TWO_PASS = 1, MGX_KERNEL_FUSED = 2 };
+
+const char *mgx_last_error(void);
+const char *mgx_version(void);
+
+/* Context = one GPU + one stream.  `stream` may be an existing hipStream_t
+ * (e.g. the caller's current stream, so that the caller's events bracket
+ * the kernels) or NULL to let the library create its own. */
+int mgx_ctx_create(int device, void *stream, mgx_ctx **out);
+int mgx_ctx_destroy(mgx_ctx *ctx);
+int mgx_ctx_sync(mgx_ctx *ctx);                                   /* [sync] */
+int mgx_ctx_set_kernel(mgx_ctx *ctx, int which);                   /* MGX_KERNEL_* */
+
+/* Level storage — replaces grid_bring_back / grid_hold_back (t_mg.f90:590-612).
+ * A level is allocated once and stays resident in HBM.  n = interior size.
+ * The slab form describes planes [z0+1, z0+n3_local] of a global level of
+ * depth n3_global (z-slab decomposition across GPUs); colours and the
+ * interior test use global z.  mgx_level_create == slab with z0 = 0 and
+ * n3_local = n3_global. */
+int mgx_level_create(mgx_ctx *ctx, int layer, const int32_t n[3], int elem_bytes, mgx_level **out);
+int mgx_level_create_slab(mgx_ctx *ctx, int layer, const int32_t n_global[3], int32_t z0,
+                          int32_t n3_local, int elem_bytes, mgx_level **out);
+int mgx_level_destroy(mgx_level *lv);
+/* grid_bring_back: the reference leaves V uninitialised (t_mg.f90:608); here it is defined as zero */
+int mgx_level_bring_back(mgx_level *lv);
+/* grid_hold_back: keeps the storage (levels stay resident); marks the field undefined */
+int mgx_level_release(mgx_level *lv);
+
+/* fields of mg_grid the operators read: sor (t_mg.f90:32), a(3) (:33), BC(2,3) (:53)
+ * given as A0,A1,B0,B1,C0,C1 */
+int mgx_level_set_params(mgx_level *lv, double sor, const double a[3], const int32_t bc[6]);
+/* box table (t_mg.f90:46-47,62-72); replaces the per-cell scans of is_constant /
+ * val_constant / val_rho (t_mg.f90:634-687) */
+int mgx_level_set_boxes(mgx_level *lv, int32_t nbox, const int32_t *place /*[nbox][6]*/,
+                        const double *val, const double *rho, const int32_t *constant);
+
+/* grid_setup (t_mg.f90:465-588): optional zero, imprint constant boxes, fill the
+ * six ghost faces in the reference's order.  Call sites replaced:
+ * m_gs_CDS.F90:36,39,76; mg.F90:96 (the ones inside restriction/prolongation are
+ * part of mgx_restrict / mgx_prolong). */
+int mgx_level_setup(mgx_level *lv, int init);
+
+/* gs_step / gs (m_gs_CDS.F90:296-345) as red-black sweeps: `nsweeps` full sweeps
+ * (black = odd x+y+z first, then red) are enqueued; the reductions named in
+ * `reduce` (MGX_RED_ERR: max (vv-V)^2; MGX_RED_SUM: sum |V| over the interior,
+ * i.e. the grid_sum that follows gs_step at m_gs_CDS.F90:206) are taken on the
+ * LAST sweep and fetched with mgx_level_result.  Replaces m_gs_CDS.F90:202,241,272. */
+int mgx_level_sweep(mgx_level *lv, int nsweeps, int reduce);
+/* one colour only (parity 1 = odd x+y+z, 0 = even), planes [zlo,zhi] (local, 1-based,
+ * inclusive) — the building block for halo-exchange overlap across z-slabs.
+ * Reductions accumulate into the level's result until mgx_level_result_reset. */
+int mgx_level_half_sweep(mgx_level *lv, int parity, int32_t zlo, int32_t zhi, int reduce);
+int mgx_level_result_reset(mgx_level *lv);
+/* [sync] results of the last sweep: err_sq_max = max (vv-V)^2 (grid%err**2 before the sqrt
+ * of m_gs_CDS.F90:313), abs_sum as mgx_level_abs_sum.  Either pointer may be NULL.
+ * sum_limbs (may be NULL) receives the exact integer sum, see mgx_level_abs_sum_limbs. */
+int mgx_level_result(mgx_level *lv, double *err_sq_max, double *abs_sum, uint64_t sum_limbs[2]);
+
+/* grid_sum (t_mg.f90:794-814), call sites m_gs_CDS.F90:136,149,195,206,238,245,269,275.
+ * Defined order-independently: sum of floor(|V|*2^72) as a 128-bit integer,
+ * rounded once to double — the same bits for any tiling or GPU count. [sync] */
+int mgx_level_abs_sum(mgx_level *lv, double *sum);
+int mgx_level_abs_sum_limbs(mgx_level *lv, uint64_t limbs[2]);    /* [sync] low, high word */
+/* helper: 128-bit integer (units of 2^-72) -> nearest-even double */
+double mgx_limbs_to_double(const uint64_t limbs[2]);
+
+/* grid_non_constant_elem (t_mg.f90:816-834), call sites m_gs_CDS.F90:134,191,237,268:
+ * interior cells of the GLOBAL level outside every constant box (host arithmetic on the
+ * box table, no device pass). */
+int mgx_level_count_nonconst(mgx_level *lv, int64_t *count);
+/* grid_tolerance (t_mg.f90:857-868): tol * |max val - min val| over all box slots, in the
+ * level's precision */
+int mgx_level_tolerance(mgx_level *lv, double tol, double *out);
+
+/* grid_restriction (t_mg_interp.f90:9-21,122-293) incl. its trailing grid_setup(child);
+ * call sites m_gs_CDS.F90:122,254.  `method` = the parent's RES_method. */
+int mgx_restrict(mgx_level *parent, mgx_level *child, int method);
+/* grid_prolongation (t_mg_interp.f90:23-35,296-469) incl. its trailing grid_setup(parent);
+ * call sites m_gs_CDS.F90:96,171,286.  `method` = the child's PRO_method. */
+int mgx_prolong(mgx_level *child, mgx_level *parent, int method);
+
+/* host <-> device copies of the whole ghosted field (reads of grid%V in
+ * m_mg_save.F90:99,174,244,280; writes when the caller supplies an initial guess,
+ * m_gs_CDS.F90:30-40).  For a slab level the host array holds local planes
+ * 0..n3_local+1. [sync] */
+int mgx_level_upload(mgx_level *lv, const void *host);
+int mgx_level_download(mgx_level *lv, void *host);
+
+/* z-slab plumbing: device address and byte size of `count` consecutive local planes
+ * starting at `z` (valid z: -1 .. n3_local+2; planes are contiguous, rows padded to
+ * the device pitch), for halo exchange by the host's communication layer. */
+int mgx_level_plane_ptr(mgx_level *lv, int32_t z, int32_t count, void **ptr, size_t *bytes);
+/* tell the library that planes outside 1..n3_local were rewritten behind its back */
+int mgx_level_halo_written(mgx_level *lv);
+
+/* introspection for tests and benchmarks */
+int mgx_level_info(mgx_level *lv, int32_t n[3], int32_t *elem_bytes, int64_t *pitch_x,
+                   int64_t *pitch_plane, int64_t *device_bytes);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MGX_H */

@@ -1,0 +1,700 @@
+// mgx — host side of the C ABI declared in include/mgx.h (gfx950 only).
+#include "../../include/mgx.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstdarg>
+#include <cstdio>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "mgx_kernels.hpp"
+#include "mgx_fused.hpp"
+
+// ------------------------------------------------------------------------------------------------
+// errors
+
+static thread_local char g_err[512] = "";
+
+static int fail(int code, const char *fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof g_err, fmt, ap);
+  va_end(ap);
+  return code;
+}
+
+#define HIP_TRY(expr)                                                                              \
+  do {                                                                                             \
+    hipError_t e_ = (expr);                                                                        \
+    if (e_ != hipSuccess)                                                                          \
+      return fail(e_ == hipErrorOutOfMemory ? MGX_ENOMEM : MGX_EHIP, "%s failed: %s (%s:%d)", #expr, \
+                  hipGetErrorString(e_), __FILE__, __LINE__);                                      \
+  } while (0)
+
+#define TRY(expr)          \
+  do {                     \
+    int r_ = (expr);       \
+    if (r_ != MGX_OK) return r_; \
+  } while (0)
+
+extern "C" const char *mgx_last_error(void) { return g_err; }
+extern "C" const char *mgx_version(void) { return "mgx 0.1 (gfx950)"; }
+
+// ------------------------------------------------------------------------------------------------
+// objects
+
+struct mgx_ctx {
+  int device = 0;
+  hipStream_t stream = nullptr;
+  bool own_stream = false;
+  int kernel = MGX_KERNEL_AUTO;
+  u64 *h_res = nullptr;        // pinned read-back buffer
+};
+
+struct mgx_level {
+  mgx_ctx *ctx = nullptr;
+  int layer = 0;
+  int elem = 8;
+  MgxGeom g{};
+  long long elems = 0;         // allocated elements per buffer
+  void *buf[2] = {nullptr, nullptr};
+  int cur = 0;
+  bool shell_synced = false;   // buf[1-cur] holds the same ghost shell as buf[cur]
+  bool defined = false;        // field content is meaningful
+  // parameters
+  double sor = 1.8;
+  double a[3] = {1.0 / 3, 1.0 / 3, 1.0 / 3};
+  int bc[6] = {2, 2, 2, 2, 2, 2};
+  bool params_set = false;
+  std::vector<MgxBox> boxes;   // host copy (values already rounded to the level's precision)
+  MgxBox *d_boxes = nullptr;
+  int nbox = 0;
+  long long count_cache = -1;
+  u64 *d_res = nullptr;        // MGX_RES_WORDS words
+};
+
+static inline mgx_ctx *C(mgx_level *lv) { return lv->ctx; }
+
+template <typename T>
+static MgxSweepParams<T> make_params(const mgx_level *lv) {
+  MgxSweepParams<T> p;
+  p.s2 = (T)lv->sor;                 // m_gs_CDS.F90:326
+  p.s1 = (T)1 - p.s2;                // m_gs_CDS.F90:327
+  for (int i = 0; i < 3; ++i) p.a[i] = (T)lv->a[i];
+  // val (m_gs_CDS.F90:729-735) with every rho = 1: r = 1*a(dir), normalised by the sequential sum
+  T r[6] = {(T)1 * p.a[0], (T)1 * p.a[0], (T)1 * p.a[1], (T)1 * p.a[1], (T)1 * p.a[2], (T)1 * p.a[2]};
+  T s = r[0];
+  for (int i = 1; i < 6; ++i) s = s + r[i];
+  p.w[0] = r[0] / s;
+  p.w[1] = r[2] / s;
+  p.w[2] = r[4] / s;
+  return p;
+}
+
+static int set_device(mgx_ctx *ctx) {
+  HIP_TRY(hipSetDevice(ctx->device));
+  return MGX_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// context
+
+extern "C" int mgx_ctx_create(int device, void *stream, mgx_ctx **out) {
+  if (!out) return fail(MGX_EINVAL, "mgx_ctx_create: out is NULL");
+  int ndev = 0;
+  HIP_TRY(hipGetDeviceCount(&ndev));
+  if (device < 0 || device >= ndev) return fail(MGX_EINVAL, "mgx_ctx_create: device %d not in [0,%d)", device, ndev);
+  HIP_TRY(hipSetDevice(device));
+  hipDeviceProp_t prop;
+  HIP_TRY(hipGetDeviceProperties(&prop, device));
+  if (strncmp(prop.gcnArchName, "gfx950", 6) != 0)
+    return fail(MGX_EINVAL, "mgx_ctx_create: device %d is %s; this library is built for gfx950 only", device,
+                prop.gcnArchName);
+  mgx_ctx *c = new mgx_ctx();
+  c->device = device;
+  if (stream) {
+    c->stream = (hipStream_t)stream;
+  } else {
+    hipError_t e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) { delete c; return fail(MGX_EHIP, "hipStreamCreate: %s", hipGetErrorString(e)); }
+    c->own_stream = true;
+  }
+  hipError_t e = hipHostMalloc((void **)&c->h_res, MGX_RES_WORDS * sizeof(u64), hipHostMallocDefault);
+  if (e != hipSuccess) { delete c; return fail(MGX_EHIP, "hipHostMalloc: %s", hipGetErrorString(e)); }
+  *out = c;
+  return MGX_OK;
+}
+
+extern "C" int mgx_ctx_destroy(mgx_ctx *ctx) {
+  if (!ctx) return MGX_OK;
+  hipSetDevice(ctx->device);
+  hipStreamSynchronize(ctx->stream);
+  if (ctx->own_stream) hipStreamDestroy(ctx->stream);
+  if (ctx->h_res) hipHostFree(ctx->h_res);
+  delete ctx;
+  return MGX_OK;
+}
+
+extern "C" int mgx_ctx_sync(mgx_ctx *ctx) {
+  if (!ctx) return fail(MGX_EINVAL, "mgx_ctx_sync: ctx is NULL");
+  TRY(set_device(ctx));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  return MGX_OK;
+}
+
+extern "C" int mgx_ctx_set_kernel(mgx_ctx *ctx, int which) {
+  if (!ctx) return fail(MGX_EINVAL, "mgx_ctx_set_kernel: ctx is NULL");
+  if (which < MGX_KERNEL_AUTO || which > MGX_KERNEL_FUSED) return fail(MGX_EINVAL, "mgx_ctx_set_kernel: %d", which);
+  ctx->kernel = which;
+  return MGX_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// level storage
+
+extern "C" int mgx_level_create_slab(mgx_ctx *ctx, int layer, const int32_t n[3], int32_t z0, int32_t n3_local,
+                                     int elem_bytes, mgx_level **out) {
+  if (!ctx || !n || !out) return fail(MGX_EINVAL, "mgx_level_create: NULL argument");
+  if (elem_bytes != 4 && elem_bytes != 8) return fail(MGX_EINVAL, "mgx_level_create: elem_bytes %d (want 4 or 8)", elem_bytes);
+  if (n[0] < 1 || n[1] < 1 || n[2] < 1) return fail(MGX_EINVAL, "mgx_level_create: n = %d %d %d", n[0], n[1], n[2]);
+  if (z0 < 0 || n3_local < 1 || z0 + n3_local > n[2])
+    return fail(MGX_EINVAL, "mgx_level_create: slab z0=%d n3_local=%d outside global depth %d", z0, n3_local, n[2]);
+  if ((long long)n[0] + 2 > (1 << 24) || (long long)n[1] + 2 > (1 << 24) || (long long)n[2] + 4 > (1 << 24))
+    return fail(MGX_ELIMIT, "mgx_level_create: a dimension exceeds 2^24");
+  TRY(set_device(ctx));
+  mgx_level *lv = new mgx_level();
+  lv->ctx = ctx;
+  lv->layer = layer;
+  lv->elem = elem_bytes;
+  const int align = 128 / elem_bytes;      // elements per 128 bytes
+  MgxGeom &g = lv->g;
+  g.n1 = n[0]; g.n2 = n[1]; g.n3 = n3_local; g.n3g = n[2]; g.z0 = z0;
+  g.px = ((n[0] + 2 + align - 1) / align) * align;
+  g.py = n[1] + 2;
+  g.pz = (long long)g.px * g.py;
+  g.front = align;
+  lv->elems = g.front + g.pz * (long long)(n3_local + 4) + align;
+  const size_t bytes = (size_t)lv->elems * elem_bytes;
+  for (int i = 0; i < 2; ++i) {
+    hipError_t e = hipMalloc(&lv->buf[i], bytes);
+    if (e != hipSuccess) {
+      if (i) hipFree(lv->buf[0]);
+      delete lv;
+      return fail(MGX_ENOMEM, "mgx_level_create: hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
+    }
+  }
+  hipError_t e = hipMalloc((void **)&lv->d_res, MGX_RES_WORDS * sizeof(u64));
+  if (e != hipSuccess) { hipFree(lv->buf[0]); hipFree(lv->buf[1]); delete lv; return fail(MGX_ENOMEM, "hipMalloc(result)"); }
+  HIP_TRY(hipMemsetAsync(lv->buf[0], 0, bytes, ctx->stream));
+  HIP_TRY(hipMemsetAsync(lv->buf[1], 0, bytes, ctx->stream));
+  HIP_TRY(hipMemsetAsync(lv->d_res, 0, MGX_RES_WORDS * sizeof(u64), ctx->stream));
+  lv->shell_synced = true;
+  lv->defined = true;
+  *out = lv;
+  return MGX_OK;
+}
+
+extern "C" int mgx_level_create(mgx_ctx *ctx, int layer, const int32_t n[3], int elem_bytes, mgx_level **out) {
+  if (!n) return fail(MGX_EINVAL, "mgx_level_create: n is NULL");
+  return mgx_level_create_slab(ctx, layer, n, 0, n[2], elem_bytes, out);
+}
+
+extern "C" int mgx_level_destroy(mgx_level *lv) {
+  if (!lv) return MGX_OK;
+  hipSetDevice(lv->ctx->device);
+  hipStreamSynchronize(lv->ctx->stream);
+  hipFree(lv->buf[0]);
+  hipFree(lv->buf[1]);
+  hipFree(lv->d_res);
+  if (lv->d_boxes) hipFree(lv->d_boxes);
+  delete lv;
+  return MGX_OK;
+}
+
+extern "C" int mgx_level_bring_back(mgx_level *lv) {
+  if (!lv) return fail(MGX_EINVAL, "mgx_level_bring_back: NULL level");
+  TRY(set_device(C(lv)));
+  HIP_TRY(hipMemsetAsync(lv->buf[lv->cur], 0, (size_t)lv->elems * lv->elem, C(lv)->stream));
+  lv->shell_synced = false;
+  lv->defined = true;
+  return MGX_OK;
+}
+
+extern "C" int mgx_level_release(mgx_level *lv) {
+  if (!lv) return fail(MGX_EINVAL, "mgx_level_release: NULL level");
+  lv->defined = false;
+  return MGX_OK;
+}
+
+extern "C" int mgx_level_set_params(mgx_level *lv, double sor, const double a[3], const int32_t bc[6]) {
+  if (!lv || !a || !bc) return fail(MGX_EINVAL, "mgx_level_set_params: NULL argument");
+  for (int i = 0; i < 6; ++i)
+    if (bc[i] < 1 || bc[i] > 3) return fail(MGX_EINVAL, "mgx_level_set_params: bc[%d] = %d (want 1,2,3)", i, bc[i]);
+  lv->sor = sor;
+  for (int i = 0; i < 3; ++i) lv->a[i] = a[i];
+  for (int i = 0; i < 6; ++i) lv->bc[i] = bc[i];
+  lv->params_set = true;
+  return MGX_OK;
+}
+
+extern "C" int mgx_level_set_boxes(mgx_level *lv, int32_t nbox, const int32_t *place, const double *val,
+                                   const double *rho, const int32_t *constant) {
+  if (!lv) return fail(MGX_EINVAL, "mgx_level_set_boxes: NULL level");
+  if (nbox < 0 || (nbox > 0 && (!place || !val || !rho || !constant)))
+    return fail(MGX_EINVAL, "mgx_level_set_boxes: nbox = %d with NULL table", nbox);
+  TRY(set_device(C(lv)));
+  lv->boxes.resize(nbox);
+  for (int i = 0; i < nbox; ++i) {
+    MgxBox &b = lv->boxes[i];
+    for (int d = 0; d < 3; ++d) { b.lo[d] = place[6 * i + 2 * d]; b.hi[d] = place[6 * i + 2 * d + 1]; }
+    b.constant = constant[i] != 0;
+    if (rho[i] < 0.0) return fail(MGX_EINVAL, "mgx_level_set_boxes: box %d has rho < 0 (t_mg.f90:352)", i);
+    b.val = lv->elem == 4 ? (double)(float)val[i] : val[i];   // box%val is real(grid_p)
+    b.rho = lv->elem == 4 ? (double)(float)rho[i] : rho[i];
+    b.rho_is_one = b.rho == 1.0;
+  }
+  HIP_TRY(hipStreamSynchronize(C(lv)->stream));   // kernels in flight may still read the old table
+  if (lv->d_boxes) { HIP_TRY(hipFree(lv->d_boxes)); lv->d_boxes = nullptr; }
+  if (nbox > 0) {
+    HIP_TRY(hipMalloc((void **)&lv->d_boxes, sizeof(MgxBox) * nbox));
+    HIP_TRY(hipMemcpy(lv->d_boxes, lv->boxes.data(), sizeof(MgxBox) * nbox, hipMemcpyHostToDevice));
+  }
+  lv->nbox = nbox;
+  lv->count_cache = -1;
+  return MGX_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// grid_setup
+
+template <typename T>
+static int do_faces(mgx_level *lv) {
+  const MgxGeom &g = lv->g;
+  T *V = (T *)lv->buf[lv->cur];
+  hipStream_t st = C(lv)->stream;
+  const bool z_lo_here = g.z0 == 0, z_hi_here = g.z0 + g.n3 == g.n3g;
+  const bool whole = z_lo_here && z_hi_here;
+  for (int face = 0; face < 6; ++face) {
+    const int dim = face / 2, hi = face & 1, bc = lv->bc[face];
+    const int nd = dim == 0 ? g.n1 : dim == 1 ? g.n2 : g.n3;
+    const int ghost = hi ? nd + 1 : 0;
+    int src = bc == MGX_BC_PERIODIC ? (hi ? 1 : nd) : bc == MGX_BC_NEUMANN ? (hi ? nd : 1) : -1;
+    if (dim == 2) {
+      if ((hi && !z_hi_here) || (!hi && !z_lo_here)) continue;    // inner slab face: owned by the halo exchange
+      if (bc == MGX_BC_PERIODIC && !whole) continue;              // source plane lives on another slab
+      dim3 grid((g.n1 + 2 + 255) / 256, g.n2 + 2);
+      hipLaunchKernelGGL((k_face<T>), grid, dim3(256), 0, st, V, g, dim, ghost, src, 0, 0);
+    } else {
+      const int ext = dim == 0 ? g.n2 + 2 : g.n1 + 2;
+      dim3 grid((ext + 255) / 256, g.n3 + 2);
+      hipLaunchKernelGGL((k_face<T>), grid, dim3(256), 0, st, V, g, dim, ghost, src, 0, g.n3 + 1);
+    }
+  }
+  HIP_TRY(hipGetLastError());
+  return MGX_OK;
+}
+
+template <typename T>
+static int do_setup(mgx_level *lv, int init) {
+  const MgxGeom &g = lv->g;
+  hipStream_t st = C(lv)->stream;
+  T *V = (T *)lv->buf[lv->cur];
+  if (init) HIP_TRY(hipMemsetAsync(V, 0, (size_t)lv->elems * lv->elem, st));
+  bool any_const = false;
+  for (const MgxBox &b : lv->boxes) any_const |= b.constant != 0;
+  if (any_const) {
+    dim3 grid(64, lv->nbox);
+    hipLaunchKernelGGL((k_box_imprint<T>), grid, dim3(256), 0, st, V, g, lv->d_boxes, lv->nbox);
+  }
+  TRY(do_faces<T>(lv));
+  lv->shell_synced = false;
+  lv->defined = true;
+  return MGX_OK;
+}
+
+extern "C" int mgx_level_setup(mgx_level *lv, int init) {
+  if (!lv) return fail(MGX_EINVAL, "mgx_level_setup: NULL level");
+  if (!lv->params_set) return fail(MGX_ESTATE, "mgx_level_setup: mgx_level_set_params not called");
+  TRY(set_device(C(lv)));
+  return lv->elem == 4 ? do_setup<float>(lv, init) : do_setup<double>(lv, init);
+}
+
+// ------------------------------------------------------------------------------------------------
+// sweeps
+
+static int reset_result(mgx_level *lv) {
+  HIP_TRY(hipMemsetAsync(lv->d_res, 0, MGX_RES_WORDS * sizeof(u64), C(lv)->stream));
+  return MGX_OK;
+}
+
+extern "C" int mgx_level_result_reset(mgx_level *lv) {
+  if (!lv) return fail(MGX_EINVAL, "mgx_level_result_reset: NULL level");
+  TRY(set_device(C(lv)));
+  return reset_result(lv);
+}
+
+template <typename T>
+static int launch_half(mgx_level *lv, int parity, int zlo, int zhi, int reduce) {
+  const MgxGeom &g = lv->g;
+  constexpr int ZB = 8;
+  const int pairs = (g.n1 + 1) / 2;
+  dim3 grid((pairs + 63) / 64, (g.n2 + 3) / 4, (zhi - zlo + 1 + ZB - 1) / ZB);
+  hipLaunchKernelGGL((k_half_sweep<T, ZB>), grid, dim3(256), 0, C(lv)->stream, (T *)lv->buf[lv->cur], g,
+                     make_params<T>(lv), lv->d_boxes, lv->nbox, parity, zlo, zhi, reduce, lv->d_res);
+  HIP_TRY(hipGetLastError());
+  return MGX_OK;
+}
+
+template <typename T>
+static int sync_shell(mgx_level *lv) {
+  if (lv->shell_synced) return MGX_OK;
+  const MgxGeom &g = lv->g;
+  dim3 grid(std::max(1, std::min(8, (g.n1 + 2 + 255) / 256)), g.n2 + 2, g.n3 + 4);
+  hipLaunchKernelGGL((k_copy_shell<T>), grid, dim3(256), 0, C(lv)->stream, (const T *)lv->buf[lv->cur],
+                     (T *)lv->buf[1 - lv->cur], g);
+  HIP_TRY(hipGetLastError());
+  lv->shell_synced = true;
+  return MGX_OK;
+}
+
+template <typename T>
+static int do_sweeps(mgx_level *lv, int nsweeps, int reduce) {
+  const MgxGeom &g = lv->g;
+  int which = C(lv)->kernel;
+  if (which == MGX_KERNEL_AUTO) which = mgx_fused_supported<T>(g) ? MGX_KERNEL_FUSED : MGX_KERNEL_TWO_PASS;
+  if (which == MGX_KERNEL_FUSED && !mgx_fused_supported<T>(g))
+    return fail(MGX_ELIMIT, "mgx_level_sweep: fused kernel does not support this level shape");
+  for (int s = 0; s < nsweeps; ++s) {
+    const int red = (s == nsweeps - 1) ? reduce : 0;
+    if (red) TRY(reset_result(lv));
+    if (which == MGX_KERNEL_FUSED) {
+      TRY(sync_shell<T>(lv));
+      TRY((mgx_fused_launch<T>((const T *)lv->buf[lv->cur], (T *)lv->buf[1 - lv->cur], g, make_params<T>(lv),
+                               lv->d_boxes, lv->nbox, red, lv->d_res, C(lv)->stream)));
+      HIP_TRY(hipGetLastError());
+      lv->cur = 1 - lv->cur;
+    } else {
+      TRY(launch_half<T>(lv, 1, 1, g.n3, red));
+      TRY(launch_half<T>(lv, 0, 1, g.n3, red));
+    }
+  }
+  return MGX_OK;
+}
+
+extern "C" int mgx_level_sweep(mgx_level *lv, int nsweeps, int reduce) {
+  if (!lv) return fail(MGX_EINVAL, "mgx_level_sweep: NULL level");
+  if (nsweeps < 0) return fail(MGX_EINVAL, "mgx_level_sweep: nsweeps = %d", nsweeps);
+  if (!lv->params_set) return fail(MGX_ESTATE, "mgx_level_sweep: mgx_level_set_params not called");
+  if (!lv->defined) return fail(MGX_ESTATE, "mgx_level_sweep: level %d was released", lv->layer);
+  if (lv->g.n3 != lv->g.n3g) return fail(MGX_ESTATE, "mgx_level_sweep: slab levels are swept colour by colour (mgx_level_half_sweep)");
+  TRY(set_device(C(lv)));
+  return lv->elem == 4 ? do_sweeps<float>(lv, nsweeps, reduce) : do_sweeps<double>(lv, nsweeps, reduce);
+}
+
+extern "C" int mgx_level_half_sweep(mgx_level *lv, int parity, int32_t zlo, int32_t zhi, int reduce) {
+  if (!lv) return fail(MGX_EINVAL, "mgx_level_half_sweep: NULL level");
+  if (parity != 0 && parity != 1) return fail(MGX_EINVAL, "mgx_level_half_sweep: parity = %d", parity);
+  if (zlo < 1 || zhi > lv->g.n3) return fail(MGX_EINVAL, "mgx_level_half_sweep: planes [%d,%d] outside [1,%d]", zlo, zhi, lv->g.n3);
+  if (!lv->params_set) return fail(MGX_ESTATE, "mgx_level_half_sweep: mgx_level_set_params not called");
+  if (zlo > zhi) return MGX_OK;
+  TRY(set_device(C(lv)));
+  return lv->elem == 4 ? launch_half<float>(lv, parity, zlo, zhi, reduce) : launch_half<double>(lv, parity, zlo, zhi, reduce);
+}
+
+// 128-bit integer (units 2^-72) -> nearest-even double
+extern "C" double mgx_limbs_to_double(const uint64_t limbs[2]) {
+  unsigned __int128 v = ((unsigned __int128)limbs[1] << 64) | limbs[0];
+  if (v == 0) return 0.0;
+  int msb = 127;
+  while (!((v >> msb) & 1)) --msb;
+  if (msb <= 52) return std::ldexp((double)(uint64_t)v, -MGX_SUM_Q);
+  const int drop = msb - 52;
+  uint64_t mant = (uint64_t)(v >> drop);
+  const unsigned __int128 rem = v & ((((unsigned __int128)1) << drop) - 1);
+  const unsigned __int128 half = ((unsigned __int128)1) << (drop - 1);
+  if (rem > half || (rem == half && (mant & 1))) mant += 1;
+  return std::ldexp((double)mant, drop - MGX_SUM_Q);
+}
+
+static int fetch_result(mgx_level *lv, double *err, double *sum, uint64_t limbs_out[2]) {
+  mgx_ctx *c = C(lv);
+  HIP_TRY(hipMemcpyAsync(c->h_res, lv->d_res, MGX_RES_WORDS * sizeof(u64), hipMemcpyDeviceToHost, c->stream));
+  HIP_TRY(hipStreamSynchronize(c->stream));
+  const u64 *r = c->h_res;
+  if (err) { double e; memcpy(&e, &r[0], 8); *err = e; }
+  unsigned __int128 v = 0;
+  for (int k = 3; k >= 0; --k) v = (v << 32) + r[1 + k];   // digits may exceed 32 bits: plain positional sum
+  uint64_t limbs[2] = {(uint64_t)v, (uint64_t)(v >> 64)};
+  if (limbs_out) { limbs_out[0] = limbs[0]; limbs_out[1] = limbs[1]; }
+  if (sum) *sum = r[5] ? std::nan("") : mgx_limbs_to_double(limbs);
+  return MGX_OK;
+}
+
+extern "C" int mgx_level_result(mgx_level *lv, double *err_sq_max, double *abs_sum, uint64_t sum_limbs[2]) {
+  if (!lv) return fail(MGX_EINVAL, "mgx_level_result: NULL level");
+  TRY(set_device(C(lv)));
+  return fetch_result(lv, err_sq_max, abs_sum, sum_limbs);
+}
+
+template <typename T>
+static int launch_abs_sum(mgx_level *lv) {
+  const MgxGeom &g = lv->g;
+  const long long rows = (long long)g.n2 * g.n3;
+  const int blocks = (int)std::max(1LL, std::min(4096LL, (rows + 3) / 4));
+  hipLaunchKernelGGL((k_abs_sum<T>), dim3(blocks), dim3(256), 0, C(lv)->stream, (const T *)lv->buf[lv->cur], g, 1,
+                     g.n3, lv->d_res);
+  HIP_TRY(hipGetLastError());
+  return MGX_OK;
+}
+
+extern "C" int mgx_level_abs_sum_limbs(mgx_level *lv, uint64_t limbs[2]) {
+  if (!lv || !limbs) return fail(MGX_EINVAL, "mgx_level_abs_sum_limbs: NULL argument");
+  if (!lv->defined) return fail(MGX_ESTATE, "mgx_level_abs_sum: level %d was released", lv->layer);
+  TRY(set_device(C(lv)));
+  TRY(reset_result(lv));
+  TRY(lv->elem == 4 ? launch_abs_sum<float>(lv) : launch_abs_sum<double>(lv));
+  double s;
+  TRY(fetch_result(lv, nullptr, &s, limbs));
+  if (std::isnan(s)) return fail(MGX_ELIMIT, "mgx_level_abs_sum: a value is >= 2^20 or not finite");
+  return MGX_OK;
+}
+
+extern "C" int mgx_level_abs_sum(mgx_level *lv, double *sum) {
+  if (!sum) return fail(MGX_EINVAL, "mgx_level_abs_sum: sum is NULL");
+  uint64_t limbs[2];
+  TRY(mgx_level_abs_sum_limbs(lv, limbs));
+  *sum = mgx_limbs_to_double(limbs);
+  return MGX_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// host arithmetic on the box table
+
+// grid_non_constant_elem (t_mg.f90:816-834): N - |union of constant boxes clipped to the interior|
+extern "C" int mgx_level_count_nonconst(mgx_level *lv, int64_t *count) {
+  if (!lv || !count) return fail(MGX_EINVAL, "mgx_level_count_nonconst: NULL argument");
+  if (lv->count_cache < 0) {
+    const MgxGeom &g = lv->g;
+    const int nn[3] = {g.n1, g.n2, g.n3g};
+    struct B { int lo[3], hi[3]; };
+    std::vector<B> bs;
+    for (const MgxBox &b : lv->boxes) {
+      if (!b.constant) continue;
+      B c;
+      bool empty = false;
+      for (int d = 0; d < 3; ++d) {
+        c.lo[d] = std::max(b.lo[d], 1);
+        c.hi[d] = std::min(b.hi[d], nn[d]);
+        empty |= c.lo[d] > c.hi[d];
+      }
+      if (!empty) bs.push_back(c);
+    }
+    // coordinate compression in x and y, interval union in z
+    std::vector<int> xs, ys;
+    for (const B &b : bs) { xs.push_back(b.lo[0]); xs.push_back(b.hi[0] + 1); ys.push_back(b.lo[1]); ys.push_back(b.hi[1] + 1); }
+    std::sort(xs.begin(), xs.end()); xs.erase(std::unique(xs.begin(), xs.end()), xs.end());
+    std::sort(ys.begin(), ys.end()); ys.erase(std::unique(ys.begin(), ys.end()), ys.end());
+    long long covered = 0;
+    std::vector<std::pair<int, int>> iv;
+    for (size_t i = 0; i + 1 < xs.size(); ++i)
+      for (size_t j = 0; j + 1 < ys.size(); ++j) {
+        iv.clear();
+        for (const B &b : bs)
+          if (b.lo[0] <= xs[i] && xs[i] <= b.hi[0] && b.lo[1] <= ys[j] && ys[j] <= b.hi[1]) iv.push_back({b.lo[2], b.hi[2]});
+        if (iv.empty()) continue;
+        std::sort(iv.begin(), iv.end());
+        long long len = 0;
+        int cl = iv[0].first, ch = iv[0].second;
+        for (size_t k = 1; k < iv.size(); ++k) {
+          if (iv[k].first <= ch + 1) ch = std::max(ch, iv[k].second);
+          else { len += ch - cl + 1; cl = iv[k].first; ch = iv[k].second; }
+        }
+        len += ch - cl + 1;
+        covered += len * (long long)(xs[i + 1] - xs[i]) * (long long)(ys[j + 1] - ys[j]);
+      }
+    lv->count_cache = (long long)g.n1 * g.n2 * g.n3g - covered;
+  }
+  *count = lv->count_cache;
+  return MGX_OK;
+}
+
+// grid_tolerance (t_mg.f90:857-868)
+extern "C" int mgx_level_tolerance(mgx_level *lv, double tol, double *out) {
+  if (!lv || !out) return fail(MGX_EINVAL, "mgx_level_tolerance: NULL argument");
+  if (lv->elem == 4) {
+    float vmax = -__FLT_MAX__, vmin = __FLT_MAX__;
+    for (const MgxBox &b : lv->boxes) { vmin = std::min(vmin, (float)b.val); vmax = std::max(vmax, (float)b.val); }
+    *out = (double)(float)(tol * (double)std::fabs(vmax - vmin));
+  } else {
+    double vmax = -__DBL_MAX__, vmin = __DBL_MAX__;
+    for (const MgxBox &b : lv->boxes) { vmin = std::min(vmin, b.val); vmax = std::max(vmax, b.val); }
+    *out = tol * std::fabs(vmax - vmin);
+  }
+  return MGX_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// transfer operators
+
+static int g2g(int n1, int i1, int n2) {                 // t_mg_interp.f90:995-999
+  long long v = ((long long)i1 * n2) / n1;
+  return (int)std::max(1LL, std::min(v, (long long)n2));
+}
+
+struct DevTable {
+  int *d = nullptr;
+  ~DevTable() { if (d) hipFree(d); }
+};
+
+static int upload_table(const std::vector<int> &h, DevTable &t, hipStream_t st) {
+  HIP_TRY(hipMalloc((void **)&t.d, sizeof(int) * h.size()));
+  HIP_TRY(hipMemcpyAsync(t.d, h.data(), sizeof(int) * h.size(), hipMemcpyHostToDevice, st));
+  return MGX_OK;
+}
+
+template <typename T>
+static int launch_transfer(bool restrict_, bool half, mgx_level *src, mgx_level *dst, const int *mx, const int *my,
+                           const int *mz) {
+  const MgxGeom &gd = dst->g;
+  dim3 grid((gd.n1 + 63) / 64, (gd.n2 + 3) / 4, gd.n3);
+  hipStream_t st = C(dst)->stream;
+  const T *s = (const T *)src->buf[src->cur];
+  T *d = (T *)dst->buf[dst->cur];
+  if (restrict_ && half) hipLaunchKernelGGL((k_transfer<T, true, true>), grid, dim3(256), 0, st, s, src->g, d, gd, mx, my, mz);
+  else if (restrict_) hipLaunchKernelGGL((k_transfer<T, false, true>), grid, dim3(256), 0, st, s, src->g, d, gd, mx, my, mz);
+  else if (half) hipLaunchKernelGGL((k_transfer<T, true, false>), grid, dim3(256), 0, st, s, src->g, d, gd, mx, my, mz);
+  else hipLaunchKernelGGL((k_transfer<T, false, false>), grid, dim3(256), 0, st, s, src->g, d, gd, mx, my, mz);
+  HIP_TRY(hipGetLastError());
+  return MGX_OK;
+}
+
+static int check_pair(const char *who, mgx_level *a, mgx_level *b, int method) {
+  if (!a || !b) return fail(MGX_EINVAL, "%s: NULL level", who);
+  if (a->ctx != b->ctx) return fail(MGX_EINVAL, "%s: levels belong to different contexts", who);
+  if (a->elem != b->elem) return fail(MGX_EINVAL, "%s: levels differ in precision", who);
+  if (method != MGX_INTERP_FULL && method != MGX_INTERP_HALF) return fail(MGX_EINVAL, "%s: method %d", who, method);
+  if (!b->params_set) return fail(MGX_ESTATE, "%s: destination level has no parameters", who);
+  return MGX_OK;
+}
+
+// source planes a slab needs must be inside its allocation (local -1 .. n3+2)
+static int check_z_reach(const char *who, const std::vector<int> &mz, const mgx_level *src, const mgx_level *dst) {
+  for (int z = 1; z <= dst->g.n3; ++z) {
+    const int sg = mz[z + dst->g.z0];
+    if (sg == 0) continue;
+    const int sl = sg - src->g.z0;
+    if (sl - 1 < -1 || sl + 1 > src->g.n3 + 2)
+      return fail(MGX_ESTATE, "%s: destination plane %d needs source plane %d outside the source slab", who, z + dst->g.z0, sg);
+  }
+  return MGX_OK;
+}
+
+extern "C" int mgx_restrict(mgx_level *parent, mgx_level *child, int method) {
+  TRY(check_pair("mgx_restrict", parent, child, method));
+  if (!parent->defined) return fail(MGX_ESTATE, "mgx_restrict: parent level %d was released", parent->layer);
+  TRY(set_device(C(child)));
+  const MgxGeom &gp = parent->g, &gc = child->g;
+  std::vector<int> mx(gc.n1 + 2, 0), my(gc.n2 + 2, 0), mz(gc.n3g + 2, 0);
+  for (int cz = 1; cz <= gc.n3g; ++cz) mz[cz] = g2g(gc.n3g, cz, gp.n3g);            // t_mg_interp.f90:153,244
+  if (method == MGX_INTERP_HALF) {                                                   // :247-252
+    for (int cx = 1; cx <= gc.n1; ++cx) mx[cx] = g2g(gc.n1, cx, gp.n1);
+    for (int cy = 1; cy <= gc.n2; ++cy) my[cy] = g2g(gc.n2, cy, gp.n2);
+  } else {                                                                           // :156-161, last writer wins
+    for (int x = 2; x <= gp.n1; x += 2) mx[g2g(gp.n1, x, gc.n1)] = x;
+    for (int y = 2; y <= gp.n2; y += 2) my[g2g(gp.n2, y, gc.n2)] = y;
+  }
+  TRY(check_z_reach("mgx_restrict", mz, parent, child));
+  DevTable tx, ty, tz;
+  hipStream_t st = C(child)->stream;
+  TRY(upload_table(mx, tx, st)); TRY(upload_table(my, ty, st)); TRY(upload_table(mz, tz, st));
+  const bool half = method == MGX_INTERP_HALF;
+  TRY(child->elem == 4 ? launch_transfer<float>(true, half, parent, child, tx.d, ty.d, tz.d)
+                       : launch_transfer<double>(true, half, parent, child, tx.d, ty.d, tz.d));
+  child->defined = true;
+  TRY(child->elem == 4 ? do_setup<float>(child, 0) : do_setup<double>(child, 0));
+  HIP_TRY(hipStreamSynchronize(st));     // tables are freed on return
+  return MGX_OK;
+}
+
+extern "C" int mgx_prolong(mgx_level *child, mgx_level *parent, int method) {
+  TRY(check_pair("mgx_prolong", child, parent, method));
+  if (!child->defined) return fail(MGX_ESTATE, "mgx_prolong: child level %d was released", child->layer);
+  TRY(set_device(C(parent)));
+  const MgxGeom &gp = parent->g, &gc = child->g;
+  std::vector<int> mx(gp.n1 + 2, 0), my(gp.n2 + 2, 0), mz(gp.n3g + 2, 0);
+  for (int px = 1; px <= gp.n1; ++px) mx[px] = g2g(gp.n1, px, gc.n1);               // t_mg_interp.f90:334,426
+  for (int py = 1; py <= gp.n2; ++py) my[py] = g2g(gp.n2, py, gc.n2);               // :330,422
+  for (int pz = 1; pz <= gp.n3g; ++pz) mz[pz] = g2g(gp.n3g, pz, gc.n3g);            // :326,418
+  TRY(check_z_reach("mgx_prolong", mz, child, parent));
+  DevTable tx, ty, tz;
+  hipStream_t st = C(parent)->stream;
+  TRY(upload_table(mx, tx, st)); TRY(upload_table(my, ty, st)); TRY(upload_table(mz, tz, st));
+  const bool half = method == MGX_INTERP_HALF;
+  TRY(parent->elem == 4 ? launch_transfer<float>(false, half, child, parent, tx.d, ty.d, tz.d)
+                        : launch_transfer<double>(false, half, child, parent, tx.d, ty.d, tz.d));
+  parent->defined = true;
+  TRY(parent->elem == 4 ? do_setup<float>(parent, 0) : do_setup<double>(parent, 0));
+  HIP_TRY(hipStreamSynchronize(st));
+  return MGX_OK;
+}
+
+// ------------------------------------------------------------------------------------------------
+// host <-> device
+
+static int copy_field(mgx_level *lv, void *host, bool to_device) {
+  const MgxGeom &g = lv->g;
+  const size_t es = lv->elem;
+  char *dev = (char *)lv->buf[lv->cur] + (size_t)(g.idx(0, 0, 0)) * es;
+  const size_t width = (size_t)(g.n1 + 2) * es;
+  const size_t height = (size_t)(g.n2 + 2) * (g.n3 + 2);
+  hipStream_t st = C(lv)->stream;
+  if (to_device) HIP_TRY(hipMemcpy2DAsync(dev, (size_t)g.px * es, host, width, width, height, hipMemcpyHostToDevice, st));
+  else HIP_TRY(hipMemcpy2DAsync(host, width, dev, (size_t)g.px * es, width, height, hipMemcpyDeviceToHost, st));
+  HIP_TRY(hipStreamSynchronize(st));
+  return MGX_OK;
+}
+
+extern "C" int mgx_level_upload(mgx_level *lv, const void *host) {
+  if (!lv || !host) return fail(MGX_EINVAL, "mgx_level_upload: NULL argument");
+  TRY(set_device(C(lv)));
+  TRY(copy_field(lv, const_cast<void *>(host), true));
+  lv->shell_synced = false;
+  lv->defined = true;
+  return MGX_OK;
+}
+
+extern "C" int mgx_level_download(mgx_level *lv, void *host) {
+  if (!lv || !host) return fail(MGX_EINVAL, "mgx_level_download: NULL argument");
+  if (!lv->defined) return fail(MGX_ESTATE, "mgx_level_download: level %d was released", lv->layer);
+  TRY(set_device(C(lv)));
+  return copy_field(lv, host, false);
+}
+
+extern "C" int mgx_level_plane_ptr(mgx_level *lv, int32_t z, int32_t count, void **ptr, size_t *bytes) {
+  if (!lv || !ptr || !bytes) return fail(MGX_EINVAL, "mgx_level_plane_ptr: NULL argument");
+  if (count < 1 || z < -1 || z + count - 1 > lv->g.n3 + 2)
+    return fail(MGX_EINVAL, "mgx_level_plane_ptr: planes [%d,%d] outside [-1,%d]", z, z + count - 1, lv->g.n3 + 2);
+  // a plane = rows y = 0..n2+1, each from its x = 0 ghost to the end of the pitch
+  *ptr = (char *)lv->buf[lv->cur] + (size_t)lv->g.idx(0, 0, z) * lv->elem;
+  *bytes = (size_t)lv->g.pz * count * lv->elem;
+  return MGX_OK;
+}
+
+extern "C" int mgx_level_halo_written(mgx_level *lv) {
+  if (!lv) return fail(MGX_EINVAL, "mgx_level_halo_written: NULL level");
+  lv->shell_synced = false;
+  return MGX_OK;
+}
+
+extern "C" int mgx_level_info(mgx_level *lv, int32_t n[3], int32_t *elem_bytes, int64_t *pitch_x, int64_t *pitch_plane,
+                              int64_t *device_bytes) {
+  if (!lv) return fail(MGX_EINVAL, "mgx_level_info: NULL level");
+  if (n) { n[0] = lv->g.n1; n[1] = lv->g.n2; n[2] = lv->g.n3; }
+  if (elem_bytes) *elem_bytes = lv->elem;
+  if (pitch_x) *pitch_x = lv->g.px;
+  if (pitch_plane) *pitch_plane = lv->g.pz;
+  if (device_bytes) *device_bytes = 2 * lv->elems * lv->elem;
+  return MGX_OK;
+}

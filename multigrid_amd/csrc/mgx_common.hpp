@@ -1,0 +1,80 @@
+// Shared definitions of the mgx library: geometry of a resident level, device box table,
+// and the exact |V| accumulator used by every reduction.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+typedef unsigned long long u64;
+
+// One box of the level's table (t_mg.f90:62-72).  val and rho are stored already rounded to the
+// level's precision, widened to double.
+struct MgxBox {
+  int lo[3];
+  int hi[3];
+  int constant;
+  int rho_is_one;
+  double val;
+  double rho;
+};
+
+// Device layout of a level.  Element (x,y,z), x in [0,n1+1], y in [0,n2+1], local z in [-1,n3+2]:
+//   idx = front + (x-1) + px*(y + py*(z+1))
+// px is a multiple of 128 bytes and x = 1 sits on a 128-byte boundary, so interior rows are
+// aligned; the x = 0 ghost lives in the last padding slot of the previous row.  Local planes 0
+// and n3+1 are the z ghosts (or the neighbour slab's boundary planes), -1 and n3+2 the second
+// halo planes a fused black+red pass over a slab needs.
+struct MgxGeom {
+  int n1, n2, n3;      // local interior size
+  int n3g;             // global depth
+  int z0;              // global z = local z + z0
+  int px, py;          // row pitch (elements), rows per plane
+  long long pz;        // plane pitch (elements) = px*py
+  long long front;     // leading pad (elements)
+  __host__ __device__ inline long long idx(int x, int y, int z) const {
+    return front + (long long)(x - 1) + (long long)px * ((long long)y + (long long)py * (long long)(z + 1));
+  }
+};
+
+template <typename T>
+struct MgxSweepParams {
+  T s1, s2;        // sor(1) = 1 - omega, sor(2) = omega   (m_gs_CDS.F90:326-327)
+  T a[3];          // grid%a
+  T w[3];          // a(dir)/sum for a cell whose six neighbours all have rho = 1
+};
+
+// ---- exact |V| accumulation -------------------------------------------------------------------
+// acc += floor(|v| * 2^72) in 128 bits.  |v| >= 2^20 or non-finite raises ovf (the sum of 2^34
+// such cells would no longer fit).  Pure integer arithmetic: any association gives the same bits.
+#define MGX_SUM_Q 72
+
+__host__ __device__ inline void mgx_exact_add(u64 &lo, u64 &hi, double a, unsigned &ovf) {
+  u64 bits;
+#if defined(__HIP_DEVICE_COMPILE__)
+  bits = (u64)__double_as_longlong(a);
+#else
+  __builtin_memcpy(&bits, &a, 8);
+#endif
+  bits &= 0x7FFFFFFFFFFFFFFFull;
+  int e = (int)(bits >> 52);
+  u64 m = bits & 0x000FFFFFFFFFFFFFull;
+  if (e >= 1023 + 20) { ovf = 1u; return; }
+  if (e == 0) e = 1; else m |= 1ull << 52;
+  const int sh = e - 1075 + MGX_SUM_Q;   // in [-1002, 39]
+  u64 alo, ahi;
+  if (sh >= 0) {
+    alo = m << sh;
+    ahi = (m >> 1) >> (63 - sh);
+  } else {
+    alo = (sh > -64) ? (m >> (-sh)) : 0ull;
+    ahi = 0ull;
+  }
+  lo += alo;
+  hi += ahi + (lo < alo ? 1ull : 0ull);
+}
+
+// The device-side result record of a level (u64 words):
+//   [0] max (vv-V)^2 as the bit pattern of a non-negative double (monotone as an integer)
+//   [1..4] the 128-bit sum as four 32-bit digits kept in 64-bit words (carries deferred)
+//   [5] overflow flag of the sum
+#define MGX_RES_WORDS 8

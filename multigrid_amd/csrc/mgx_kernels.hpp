@@ -1,0 +1,378 @@
+// HIP kernels of the mgx library (gfx950, wave64).  All floating-point expressions follow the
+// reference's evaluation order literally; the translation unit is compiled with
+// -ffp-contract=off so that no multiply-add is fused.
+#pragma once
+
+#include "mgx_common.hpp"
+
+// ------------------------------------------------------------------------------------------------
+// block-wide reduction of (max err, exact sum) and commit to the level's result record
+
+__device__ inline double mgx_wave_max(double v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    double t = __shfl_xor(v, o, 64);
+    v = t > v ? t : v;
+  }
+  return v;
+}
+
+__device__ inline u64 mgx_wave_add(u64 v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+// NW = waves per block.  Every thread of the block must call this.
+template <int NW>
+__device__ inline void mgx_block_commit(double err, u64 lo, u64 hi, unsigned ovf, int reduce, u64 *res) {
+  __shared__ u64 sh[NW][6];
+  const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+  if (reduce & 1) {
+    double m = mgx_wave_max(err);
+    if (lane == 0) sh[w][0] = (u64)__double_as_longlong(m);
+  }
+  if (reduce & 2) {
+    u64 d0 = mgx_wave_add(lo & 0xFFFFFFFFull);
+    u64 d1 = mgx_wave_add(lo >> 32);
+    u64 d2 = mgx_wave_add(hi & 0xFFFFFFFFull);
+    u64 d3 = mgx_wave_add(hi >> 32);
+    u64 of = mgx_wave_add((u64)ovf);
+    if (lane == 0) { sh[w][1] = d0; sh[w][2] = d1; sh[w][3] = d2; sh[w][4] = d3; sh[w][5] = of; }
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    if (reduce & 1) {
+      u64 m = sh[0][0];
+#pragma unroll
+      for (int i = 1; i < NW; ++i) m = sh[i][0] > m ? sh[i][0] : m;   // non-negative doubles order as integers
+      if (m) atomicMax(&res[0], m);
+    }
+    if (reduce & 2) {
+      u64 d[5] = {0, 0, 0, 0, 0};
+#pragma unroll
+      for (int i = 0; i < NW; ++i)
+#pragma unroll
+        for (int k = 0; k < 5; ++k) d[k] += sh[i][1 + k];
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+        if (d[k]) atomicAdd(&res[1 + k], d[k]);
+      if (d[4]) atomicAdd(&res[5], d[4]);
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// box predicates (t_mg.f90:634-710) on the device table; coordinates are GLOBAL
+
+__device__ inline bool mgx_in_box(const MgxBox &b, int x, int y, int z) {
+  return b.lo[0] <= x && x <= b.hi[0] && b.lo[1] <= y && y <= b.hi[1] && b.lo[2] <= z && z <= b.hi[2];
+}
+__device__ inline bool mgx_is_constant(const MgxBox *bx, int nb, int x, int y, int z) {
+  for (int i = 0; i < nb; ++i)
+    if (bx[i].constant && mgx_in_box(bx[i], x, y, z)) return true;
+  return false;
+}
+template <typename T>
+__device__ inline T mgx_val_rho(const MgxBox *bx, int nb, int x, int y, int z) {
+  for (int i = 0; i < nb; ++i)
+    if (mgx_in_box(bx[i], x, y, z)) return (T)bx[i].rho;
+  return (T)1;
+}
+template <typename T>
+__device__ inline T mgx_val_constant(const MgxBox *bx, int nb, int x, int y, int z) {
+  for (int i = 0; i < nb; ++i)
+    if (mgx_in_box(bx[i], x, y, z)) return (T)bx[i].val;
+  return (T)0;
+}
+
+// Does any box reach into the cell range [lo-1, hi+1] (flag 1), and does any such box carry
+// rho != 1 (flag 2)?  All arguments are wave-uniform, so this runs on the scalar unit.
+__device__ inline int mgx_classify(const MgxBox *bx, int nb, int x0, int x1, int y0, int y1, int z0, int z1) {
+  int f = 0;
+  for (int i = 0; i < nb; ++i) {
+    const bool hit = bx[i].lo[0] <= x1 + 1 && x0 - 1 <= bx[i].hi[0] && bx[i].lo[1] <= y1 + 1 &&
+                     y0 - 1 <= bx[i].hi[1] && bx[i].lo[2] <= z1 + 1 && z0 - 1 <= bx[i].hi[2];
+    if (hit) f |= bx[i].rho_is_one ? 1 : 3;
+  }
+  return f;
+}
+
+// val (m_gs_CDS.F90:718-742) for a non-constant cell whose neighbourhood may hold rho != 1
+template <typename T>
+__device__ inline T mgx_avg_general(const T vxm, const T vxp, const T vym, const T vyp, const T vzm, const T vzp,
+                                    const MgxBox *bx, int nb, int x, int y, int zg, const T a[3]) {
+  T r[6];
+  r[0] = mgx_val_rho<T>(bx, nb, x - 1, y, zg) * a[0];
+  r[1] = mgx_val_rho<T>(bx, nb, x + 1, y, zg) * a[0];
+  r[2] = mgx_val_rho<T>(bx, nb, x, y - 1, zg) * a[1];
+  r[3] = mgx_val_rho<T>(bx, nb, x, y + 1, zg) * a[1];
+  r[4] = mgx_val_rho<T>(bx, nb, x, y, zg - 1) * a[2];
+  r[5] = mgx_val_rho<T>(bx, nb, x, y, zg + 1) * a[2];
+  T s = r[0];
+  s = s + r[1]; s = s + r[2]; s = s + r[3]; s = s + r[4]; s = s + r[5];
+#pragma unroll
+  for (int i = 0; i < 6; ++i) r[i] = r[i] / s;
+  T avg = vxm * r[0] + vxp * r[1];
+  avg = avg + vym * r[2];
+  avg = avg + vyp * r[3];
+  avg = avg + vzm * r[4];
+  avg = avg + vzp * r[5];
+  return avg;
+}
+
+template <typename T>
+__device__ inline T mgx_avg_uniform(const T vxm, const T vxp, const T vym, const T vyp, const T vzm, const T vzp,
+                                    const T w[3]) {
+  T avg = vxm * w[0] + vxp * w[0];
+  avg = avg + vym * w[1];
+  avg = avg + vyp * w[1];
+  avg = avg + vzm * w[2];
+  avg = avg + vzp * w[2];
+  return avg;
+}
+
+// the new value of one cell (body of gs, m_gs_CDS.F90:335-337); cls = mgx_classify flags
+template <typename T>
+__device__ inline T mgx_cell_new(const T vc, const T vxm, const T vxp, const T vym, const T vyp, const T vzm,
+                                 const T vzp, int cls, const MgxBox *bx, int nb, int x, int y, int zg,
+                                 const MgxSweepParams<T> &p) {
+  T avg;
+  if (cls == 0) {
+    avg = mgx_avg_uniform<T>(vxm, vxp, vym, vyp, vzm, vzp, p.w);
+  } else if (mgx_is_constant(bx, nb, x, y, zg)) {
+    avg = vc;
+  } else if (cls & 2) {
+    avg = mgx_avg_general<T>(vxm, vxp, vym, vyp, vzm, vzp, bx, nb, x, y, zg, p.a);
+  } else {
+    avg = mgx_avg_uniform<T>(vxm, vxp, vym, vyp, vzm, vzp, p.w);
+  }
+  return p.s1 * vc + p.s2 * avg;
+}
+
+// ------------------------------------------------------------------------------------------------
+// two-pass smoother: one colour, in place.  Block = 64 x-pairs * 4 rows, marching ZB planes.
+
+template <typename T, int ZB>
+__global__ __launch_bounds__(256) void k_half_sweep(T *__restrict__ V, const MgxGeom g, const MgxSweepParams<T> p,
+                                                    const MgxBox *__restrict__ bx, const int nb, const int parity,
+                                                    const int zlo, const int zhi, const int reduce,
+                                                    u64 *__restrict__ res) {
+  const int lane = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int pair = blockIdx.x * 64 + lane;
+  const int y = blockIdx.y * 4 + ty + 1;
+  const int zb0 = zlo + blockIdx.z * ZB;
+  const int zb1 = min(zb0 + ZB - 1, zhi);
+  const int bx0 = blockIdx.x * 128 + 1, by0 = blockIdx.y * 4 + 1;
+  const int cls = mgx_classify(bx, nb, bx0, bx0 + 127, by0, by0 + 3, zb0 + g.z0, zb1 + g.z0);
+
+  T err = (T)0;
+  u64 lo = 0, hi = 0;
+  unsigned ovf = 0;
+  if (y <= g.n2) {
+    for (int z = zb0; z <= zb1; ++z) {
+      const int zg = z + g.z0;
+      const int x = 2 * pair + 1 + ((1 + y + zg + parity) & 1);
+      if (x > g.n1) continue;
+      const long long c = g.idx(x, y, z);
+      const T vc = V[c];
+      const T vv = mgx_cell_new<T>(vc, V[c - 1], V[c + 1], V[c - g.px], V[c + g.px], V[c - g.pz], V[c + g.pz], cls,
+                                   bx, nb, x, y, zg, p);
+      const T d = vv - vc;
+      const T d2 = d * d;
+      err = d2 > err ? d2 : err;
+      V[c] = vv;
+      if (reduce & 2) mgx_exact_add(lo, hi, (double)(vv < (T)0 ? -vv : vv), ovf);
+    }
+  }
+  if (reduce) mgx_block_commit<4>((double)err, lo, hi, ovf, reduce, res);
+}
+
+// ------------------------------------------------------------------------------------------------
+// grid_sum (t_mg.f90:794-814) over local planes [zlo,zhi]; block = 256 threads, one row per wave step
+
+template <typename T>
+__global__ __launch_bounds__(256) void k_abs_sum(const T *__restrict__ V, const MgxGeom g, const int zlo,
+                                                 const int zhi, u64 *__restrict__ res) {
+  u64 lo = 0, hi = 0;
+  unsigned ovf = 0;
+  const long long rows = (long long)g.n2 * (zhi - zlo + 1);
+  const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  for (long long r = (long long)blockIdx.x * 4 + w; r < rows; r += (long long)gridDim.x * 4) {
+    const int y = (int)(r % g.n2) + 1;
+    const int z = (int)(r / g.n2) + zlo;
+    const T *row = V + g.idx(1, y, z);
+    for (int x = lane; x < g.n1; x += 64) {
+      const T v = row[x];
+      mgx_exact_add(lo, hi, (double)(v < (T)0 ? -v : v), ovf);
+    }
+  }
+  mgx_block_commit<4>(0.0, lo, hi, ovf, 2, res);
+}
+
+// ------------------------------------------------------------------------------------------------
+// grid_setup pieces (t_mg.f90:465-588)
+
+// imprint: one launch per level; blockIdx.y = box slot.  Cells inside a CONSTANT box get the value
+// of the FIRST box (any kind) that contains them (t_mg.f90:484-494 with :634-668).
+template <typename T>
+__global__ __launch_bounds__(256) void k_box_imprint(T *__restrict__ V, const MgxGeom g, const MgxBox *__restrict__ bx,
+                                                     const int nb) {
+  const MgxBox b = bx[blockIdx.y];
+  if (!b.constant) return;
+  const int x0 = max(b.lo[0], 1), x1 = min(b.hi[0], g.n1);
+  const int y0 = max(b.lo[1], 1), y1 = min(b.hi[1], g.n2);
+  const int z0 = max(b.lo[2], 1 + g.z0), z1 = min(b.hi[2], g.n3 + g.z0);   // own planes, global coords
+  if (x0 > x1 || y0 > y1 || z0 > z1) return;
+  const long long nx = x1 - x0 + 1, ny = y1 - y0 + 1, nz = z1 - z0 + 1;
+  const long long tot = nx * ny * nz;
+  for (long long i = (long long)blockIdx.x * blockDim.x + threadIdx.x; i < tot; i += (long long)gridDim.x * blockDim.x) {
+    const int x = x0 + (int)(i % nx);
+    const int y = y0 + (int)((i / nx) % ny);
+    const int zg = z0 + (int)(i / (nx * ny));
+    V[g.idx(x, y, zg - g.z0)] = mgx_val_constant<T>(bx, nb, x, y, zg);
+  }
+}
+
+// one ghost face: dim 0/1/2, side 0 = low / 1 = high.  src < 0: store zero (Dirichlet); otherwise copy
+// the plane with index `src` along dim (periodic / Neumann).  The face spans the full ghosted extent
+// of the other two dimensions, [0,n+1] (z: local planes [zfirst,zlast]).
+template <typename T>
+__global__ __launch_bounds__(256) void k_face(T *__restrict__ V, const MgxGeom g, const int dim, const int ghost,
+                                              const int src, const int zfirst, const int zlast) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  const int j = blockIdx.y;
+  int c[3], s[3];
+  if (dim == 0) {           // i = y, j = z
+    if (i > g.n2 + 1) return;
+    c[0] = ghost; c[1] = i; c[2] = zfirst + j;
+  } else if (dim == 1) {    // i = x, j = z
+    if (i > g.n1 + 1) return;
+    c[0] = i; c[1] = ghost; c[2] = zfirst + j;
+  } else {                  // i = x, j = y
+    if (i > g.n1 + 1) return;
+    c[0] = i; c[1] = j; c[2] = ghost;
+  }
+  if (dim != 2 && c[2] > zlast) return;
+  s[0] = c[0]; s[1] = c[1]; s[2] = c[2];
+  s[dim] = src;
+  V[g.idx(c[0], c[1], c[2])] = (src < 0) ? (T)0 : V[g.idx(s[0], s[1], s[2])];
+}
+
+// copy the ghost shell (x = 0, n1+1; y = 0, n2+1; z planes outside 1..n3) from one buffer to the other
+template <typename T>
+__global__ __launch_bounds__(256) void k_copy_shell(const T *__restrict__ src, T *__restrict__ dst, const MgxGeom g) {
+  const int z = (int)blockIdx.z - 1;                   // -1 .. n3+2
+  const int y = blockIdx.y;                            // 0 .. n2+1
+  const bool whole_row = (z < 1 || z > g.n3 || y == 0 || y == g.n2 + 1);
+  for (int x = blockIdx.x * blockDim.x + threadIdx.x; x <= g.n1 + 1; x += gridDim.x * blockDim.x) {
+    if (whole_row || x == 0 || x == g.n1 + 1) {
+      const long long c = g.idx(x, y, z);
+      dst[c] = src[c];
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
+// transfer operators.  Index maps (g2g, t_mg_interp.f90:995-999, and the loop structure of each
+// operator) are built on the host exactly as the reference's loops run and passed as tables:
+//   restriction: mx[cx] = parent x feeding child cx (0: child column is not written)
+//   prolongation: mx[px] = child x feeding parent px
+// z tables hold GLOBAL indices; zoff_* converts to the local planes of each level.
+
+template <typename T, bool HALF>
+__device__ inline T mgx_stencil_restrict(const T *__restrict__ V, const long long c, const long long sy,
+                                         const long long sz) {
+  const T den = HALF ? (T)56 : (T)64;
+  const T f4 = (T)1 / den, f3 = (T)2 / den, f2 = (T)4 / den, f1 = (T)8 / den;
+#define P(dx, dy, dz) V[c + (dx) + sy * (dy) + sz * (dz)]
+  T vt;
+  if (!HALF) {
+    vt = P(-1, -1, -1) * f4;
+    vt = vt + P(-1, -1, +1) * f4;
+    vt = vt + P(-1, +1, -1) * f4;
+    vt = vt + P(-1, +1, +1) * f4;
+    vt = vt + P(+1, -1, -1) * f4;
+    vt = vt + P(+1, -1, +1) * f4;
+    vt = vt + P(+1, +1, -1) * f4;
+    vt = vt + P(+1, +1, +1) * f4;
+    vt = vt + P(-1, -1, 0) * f3;
+  } else {
+    vt = P(-1, -1, 0) * f3;
+  }
+  vt = vt + P(-1, +1, 0) * f3;
+  vt = vt + P(-1, 0, -1) * f3;
+  vt = vt + P(-1, 0, +1) * f3;
+  vt = vt + P(+1, -1, 0) * f3;
+  vt = vt + P(+1, +1, 0) * f3;
+  vt = vt + P(+1, 0, -1) * f3;
+  vt = vt + P(+1, 0, +1) * f3;
+  vt = vt + P(0, -1, -1) * f3;
+  vt = vt + P(0, -1, +1) * f3;
+  vt = vt + P(0, +1, -1) * f3;
+  vt = vt + P(0, +1, +1) * f3;
+  vt = vt + P(-1, 0, 0) * f2;
+  vt = vt + P(+1, 0, 0) * f2;
+  vt = vt + P(0, -1, 0) * f2;
+  vt = vt + P(0, +1, 0) * f2;
+  vt = vt + P(0, 0, -1) * f2;
+  vt = vt + P(0, 0, +1) * f2;
+  vt = vt + P(0, 0, 0) * f1;
+  return vt;
+}
+
+template <typename T, bool HALF>
+__device__ inline T mgx_stencil_prolong(const T *__restrict__ V, const long long c, const long long sy,
+                                        const long long sz) {
+  const T den = HALF ? (T)56 : (T)64;
+  const T f4 = (T)1 / den, f3 = (T)2 / den, f2 = (T)4 / den, f1 = (T)8 / den;
+  T vt = P(0, 0, 0) * f1;
+  vt = vt + P(-1, 0, 0) * f2;
+  vt = vt + P(+1, 0, 0) * f2;
+  vt = vt + P(0, -1, 0) * f2;
+  vt = vt + P(0, +1, 0) * f2;
+  vt = vt + P(0, 0, -1) * f2;
+  vt = vt + P(0, 0, +1) * f2;
+  vt = vt + P(-1, -1, 0) * f3;
+  vt = vt + P(-1, +1, 0) * f3;
+  vt = vt + P(-1, 0, -1) * f3;
+  vt = vt + P(-1, 0, +1) * f3;
+  vt = vt + P(+1, -1, 0) * f3;
+  vt = vt + P(+1, +1, 0) * f3;
+  vt = vt + P(+1, 0, -1) * f3;
+  vt = vt + P(+1, 0, +1) * f3;
+  vt = vt + P(0, -1, -1) * f3;
+  vt = vt + P(0, -1, +1) * f3;
+  vt = vt + P(0, +1, -1) * f3;
+  vt = vt + P(0, +1, +1) * f3;
+  if (!HALF) {
+    vt = vt + P(-1, -1, -1) * f4;
+    vt = vt + P(-1, -1, +1) * f4;
+    vt = vt + P(-1, +1, -1) * f4;
+    vt = vt + P(-1, +1, +1) * f4;
+    vt = vt + P(+1, -1, -1) * f4;
+    vt = vt + P(+1, -1, +1) * f4;
+    vt = vt + P(+1, +1, -1) * f4;
+    vt = vt + P(+1, +1, +1) * f4;
+  }
+#undef P
+  return vt;
+}
+
+// generic transfer: `dst` cell (dx,dy,dz) := stencil of `src` around (mx[dx], my[dy], mz[dz]);
+// RESTRICT selects the accumulation order.  Block = 64 x * 4 y, one z plane per blockIdx.z.
+template <typename T, bool HALF, bool RESTRICT>
+__global__ __launch_bounds__(256) void k_transfer(const T *__restrict__ src, const MgxGeom gs, T *__restrict__ dst,
+                                                  const MgxGeom gd, const int *__restrict__ mx,
+                                                  const int *__restrict__ my, const int *__restrict__ mz) {
+  const int dx = blockIdx.x * 64 + (threadIdx.x & 63) + 1;
+  const int dy = blockIdx.y * 4 + (threadIdx.x >> 6) + 1;
+  const int dz = blockIdx.z + 1;                        // local plane of dst
+  if (dx > gd.n1 || dy > gd.n2) return;
+  const int sx = mx[dx], sy_ = my[dy], szg = mz[dz + gd.z0];
+  if (sx == 0 || sy_ == 0 || szg == 0) return;
+  const long long c = gs.idx(sx, sy_, szg - gs.z0);
+  const T v = RESTRICT ? mgx_stencil_restrict<T, HALF>(src, c, gs.px, gs.pz)
+                       : mgx_stencil_prolong<T, HALF>(src, c, gs.px, gs.pz);
+  dst[gd.idx(dx, dy, dz)] = v;
+}

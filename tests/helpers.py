@@ -1,0 +1,35 @@
+"""shared helpers for the tests: fixture loading and oracle Level construction"""
+import os
+
+import numpy as np
+
+from oracle import oracle as orc
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+DT = {"f32": np.float32, "f64": np.float64}
+
+
+def load(name):
+    return np.load(os.path.join(GOLDEN, name + ".npz"))
+
+
+def boxes_of(g):
+    return [orc.Box(tuple(int(v) for v in p), float(v), float(r), bool(c))
+            for p, v, r, c in zip(g["box_place"], g["box_val"], g["box_rho"], g["box_const"])]
+
+
+def level_of(g, n_key="n", boxes=None, **kw):
+    a = tuple(float(x) for x in g["a"]) if "a" in g.files else (-1, -1, -1)
+    if a[0] < 0:
+        a = (1.0 / 3.0,) * 3          # init_grid default, t_mg.f90:143
+    return orc.Level(n=tuple(int(v) for v in g[n_key]), bc=tuple(int(v) for v in g["bc"]),
+                     sor=float(g["sor"]) if "sor" in g.files else 1.8, a=a,
+                     boxes=boxes_of(g) if boxes is None else boxes, **kw)
+
+
+def bits_equal(a, b):
+    a = np.ascontiguousarray(a)
+    b = np.ascontiguousarray(b)
+    assert a.dtype == b.dtype and a.shape == b.shape, (a.dtype, b.dtype, a.shape, b.shape)
+    iv = np.uint32 if a.dtype == np.float32 else np.uint64
+    return np.array_equal(a.view(iv), b.view(iv))
