@@ -1,0 +1,239 @@
+"""Cycle control on the host: the reference's `m_gs_CDS` (src/m_gs_CDS.F90:21-315) driving the HIP
+level operators through the C ABI.
+
+Control flow, convergence tests and the arithmetic of the tests (real(grid_p)) follow the
+reference line by line; what differs is below the boundary: every level lives in HBM for the
+whole solve (grid_bring_back zero-fills instead of allocating, grid_hold_back keeps the storage),
+the sweep is red-black, and grid_sum is the order-independent exact sum.
+"""
+from __future__ import annotations
+
+from dataclasses import dataclass
+from typing import Callable, List, Optional
+
+import numpy as np
+
+from . import grid as G
+from . import lib
+
+CDS_BOTTOM_UP, CDS_W_CYCLE = 1, 2          # m_gs_CDS.F90:12-13
+
+HIST_DTYPE = np.dtype([("layer", "i4"), ("kind", "i4"), ("itt", "i4"), ("pad_", "i4"),
+                       ("tol", "f8"), ("sum", "f8"), ("err", "f8")])
+
+
+class Solver:
+    """Owns the device context and the resident levels of one hierarchy."""
+
+    def __init__(self, top: G.MgGrid, device: int = 0, stream: Optional[int] = None, ctx: Optional[lib.Context] = None,
+                 verbose: bool = False, print_sums: bool = True, max_sweeps: int = 1 << 24):
+        self.top = top
+        self.ctx = ctx if ctx is not None else lib.Context(device, stream)
+        self.own_ctx = ctx is None
+        self.verbose = verbose
+        self.print_sums = print_sums       # evaluate the print-only sums of gs_V (m_gs_CDS.F90:238,245,269,275)
+        self.max_sweeps = max_sweeps
+        self.history: List[tuple] = []
+        self.total_sweeps = 0
+        self.t = top.dtype.type
+        for g in top.levels():
+            self.attach(g)
+
+    # -- device residency -------------------------------------------------------------------------
+    def attach(self, g: G.MgGrid):
+        if g.dev is None:
+            g.dev = self.ctx.level(g.layer, [int(v) for v in g.n], g.dtype)
+        self.push_params(g)
+
+    def push_params(self, g: G.MgGrid):
+        g.dev.set_params(g.sor, [float(v) for v in g.a], g.bc6())
+        g.dev.set_boxes(*G.box_table(g))
+
+    def close(self):
+        for g in self.top.levels():
+            if g.dev is not None:
+                g.dev.close()
+                g.dev = None
+        if self.own_ctx:
+            self.ctx.close()
+
+    # -- the reference's level routines, now thin -----------------------------------------------
+    def say(self, *a):
+        if self.verbose:
+            print(*a)
+
+    def bring_back(self, g):               # grid_bring_back, t_mg.f90:601-612
+        g.dev.bring_back()
+
+    def hold_back(self, g):                # grid_hold_back, t_mg.f90:590-599
+        g.dev.release()
+
+    def setup(self, g, init: bool):        # grid_setup, t_mg.f90:465-588
+        g.dev.setup(init)
+
+    def grid_sum(self, g) -> float:        # grid_sum, t_mg.f90:794-814 → real(grid_p)
+        return self.t(g.dev.abs_sum())
+
+    def count(self, g) -> int:             # grid_non_constant_elem, t_mg.f90:816-834
+        return g.dev.count_nonconst()
+
+    def tolerance(self, g) -> float:       # grid_tolerance, t_mg.f90:857-868
+        return self.t(G.grid_tolerance(g))
+
+    def gs_steps(self, g, nsteps: int, want_sum: bool):
+        """`nsteps` × gs_step (m_gs_CDS.F90:296-315); returns the grid_sum after the last one if asked.
+        grid%err = sqrt(max dV^2) of the last sweep."""
+        if nsteps <= 0:
+            return self.grid_sum(g) if want_sum else None
+        g.itt += nsteps
+        self.total_sweeps += nsteps
+        if self.total_sweeps > self.max_sweeps:
+            raise G.MgStop(f"more than {self.max_sweeps} sweeps")
+        g.dev.sweep(nsteps, lib.RED_ERR | (lib.RED_SUM if want_sum else 0))
+        e2, s, _ = g.dev.result()
+        g.err = float(np.sqrt(self.t(e2)))
+        return self.t(s) if want_sum else None
+
+    def record(self, g, kind, tol, s):
+        self.history.append((g.layer, kind, g.itt, 0, float(tol), float(s), float(g.err)))
+
+    def history_array(self) -> np.ndarray:
+        return np.array(self.history, dtype=HIST_DTYPE)
+
+    # -- m_gs_CDS -----------------------------------------------------------------------------------
+    def mg_gs_cds(self, method: int = CDS_BOTTOM_UP, init: Optional[bool] = None):
+        """m_gs_CDS.F90:21-57"""
+        top = self.top
+        if init is None or init:
+            self.bring_back(top)
+            self.setup(top, True)
+        if method == CDS_W_CYCLE:
+            self.gs_w()
+        elif method == CDS_BOTTOM_UP:
+            self.gs_bottom_up()
+        else:
+            raise G.MgStop("Error on method used for CDS")
+
+    def gs_bottom_up(self):
+        """m_gs_CDS.F90:59-104"""
+        grid = self.top
+        while grid.child is not None:
+            grid = grid.child
+            if grid.child is None:
+                self.bring_back(grid)
+                self.setup(grid, False)
+        while grid is not None:
+            old_itt = grid.itt
+            self.grid_solve(grid)
+            self.say(f"Completed ({grid.layer}) cycle in {grid.itt - old_itt} cycles")
+            if grid.parent is not None:
+                self.bring_back(grid.parent)
+                lib.prolong(grid.dev, grid.parent.dev, grid.PRO_method)
+                self.hold_back(grid)
+            grid = grid.parent
+
+    def grid_solve(self, grid):
+        """m_gs_CDS.F90:181-218"""
+        if not grid.enabled:
+            return
+        t = self.t
+        nr = t(1) / t(self.count(grid))
+        gtol = self.tolerance(grid)
+        tol = t(gtol + t(1))
+        old_sum = self.grid_sum(grid)
+        self.say(f"Initial sum: {float(old_sum * nr):10.7f}")
+        old_itt = grid.itt
+        while tol > gtol:
+            new_sum = self.gs_steps(grid, 1, True)
+            tol = t(abs(t(old_sum - new_sum)) * nr)
+            old_sum = new_sum
+            self.record(grid, 0, tol, new_sum)
+            self.say(f" itt {grid.itt - old_itt:6d} {float(tol):10.7f} {float(new_sum * nr):10.7f} {grid.err:10.7f}")
+
+    def _leg(self, grid):
+        """steps × gs_step between two (print-only) sums: m_gs_CDS.F90:237-248 / :268-278"""
+        t = self.t
+        if self.print_sums:
+            nr = t(1) / t(self.count(grid))
+            old_sum = self.grid_sum(grid)
+            new_sum = self.gs_steps(grid, grid.steps, True)
+            tol = t(abs(t(old_sum - new_sum)) * nr)
+            self.record(grid, 1, tol, new_sum)
+            self.say(f"      {'  ' * grid.layer}{grid.steps:6d} {float(tol):10.7f} {float(new_sum * nr):10.7f}")
+        else:
+            self.gs_steps(grid, grid.steps, False)
+
+    def gs_V(self, pg, cg):
+        """m_gs_CDS.F90:220-294"""
+        grid = pg
+        while grid.layer != cg.layer:
+            if not grid.child.enabled:
+                break
+            self._leg(grid)
+            self.bring_back(grid.child)
+            lib.restrict(grid.dev, grid.child.dev, grid.RES_method)
+            self.hold_back(grid)
+            grid = grid.child
+        while True:
+            self._leg(grid)
+            if grid.layer == pg.layer:
+                break
+            if grid.parent is not None:
+                self.bring_back(grid.parent)
+                lib.prolong(grid.dev, grid.parent.dev, grid.PRO_method)
+                self.hold_back(grid)
+            grid = grid.parent
+
+    def gs_w(self):
+        """m_gs_CDS.F90:106-179.  `otol` aliases a variable assigned once (:129) until the top level has
+        been reached, and `itol` from then on (:162-166)."""
+        t = self.t
+        top = self.top
+        if top.child is None:
+            raise G.MgStop("gs_w needs at least two levels (the reference dereferences pg%child%child)")
+        pg = cg = top
+        while pg.child.child is not None:
+            if not pg.child.child.enabled:
+                break
+            self.bring_back(pg.child)
+            lib.restrict(pg.dev, pg.child.dev, pg.RES_method)
+            self.hold_back(pg)
+            pg = pg.child
+            cg = pg.child
+        tol = t(self.tolerance(pg) + t(1))
+        itol = t(0)
+        alias_itol = False
+        top_tol = self.tolerance(top)
+        while (itol if alias_itol else tol) > top_tol:
+            nr = t(t(1) / t(self.count(pg))) / t(pg.steps)
+            old_sum = self.grid_sum(pg)
+            old_itt = pg.itt
+            self.say(f"Running between {pg.layer} and {cg.layer} in {pg.steps} steps.")
+            pg_tol = self.tolerance(pg)
+            itol = t(pg_tol + t(1))
+            while itol > pg_tol:
+                self.gs_V(pg, cg)
+                new_sum = self.grid_sum(pg)
+                itol = t(abs(t(old_sum - new_sum)) * nr)
+                old_sum = new_sum
+                self.record(pg, 2, itol, new_sum)
+                self.say(f" itt {pg.itt - old_itt:6d} {float(itol):10.7f} {float(new_sum * nr):10.7f} {pg.err:10.7f}")
+            self.say(f"Completed: {pg.layer}:{cg.layer} in {pg.itt - old_itt} itt. per. lvl")
+            if pg.layer == top.layer:
+                cg = pg
+                if not alias_itol:
+                    itol = tol
+                    alias_itol = True
+            if pg.parent is not None:
+                self.bring_back(pg.parent)
+                lib.prolong(pg.dev, pg.parent.dev, pg.PRO_method)
+                self.hold_back(pg)
+                cg = pg
+                pg = pg.parent
+
+
+def mg_gs_cds(top: G.MgGrid, method: int = CDS_BOTTOM_UP, init: Optional[bool] = None, **kw) -> Solver:
+    """convenience: build a Solver, run the reference's entry point, return the solver (history, levels)"""
+    s = Solver(top, **kw)
+    s.mg_gs_cds(method, init)
+    return s

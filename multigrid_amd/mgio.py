@@ -1,0 +1,403 @@
+"""Input grammar and output writers of the reference's `mg` program, host side.
+
+`iomg_read` follows src/m_mg_io.F90:48-406 over the tokeniser of src/m_io.F90 (keyword search that
+wraps around the file once, block nesting, lower-casing), including the order in which repeated
+blocks are handled: the FIRST `begin box` / `begin layer` block of the file is processed LAST
+(m_mg_io.F90:205-266), which fixes the box slot order and therefore the first-match precedence of
+val_constant / val_rho.  `mg_save` writes the `.VMG` container of src/m_mg_save.F90:231-267.
+"""
+from __future__ import annotations
+
+import re
+import struct
+from typing import List, Optional, Tuple
+
+import numpy as np
+
+from . import grid as G
+
+
+class MgIO:
+    """type(tIO) + io_open/io_line/io_step of src/m_io.F90:31-234 over an in-memory copy of the file"""
+
+    def __init__(self, path: Optional[str] = None, text: Optional[str] = None):
+        if text is None:
+            try:
+                with open(path, "r") as f:
+                    text = f.read()
+            except OSError:
+                raise G.MgStop(f"Can not find file: {path}")
+        self.raw = text.splitlines()
+        self.il = 0
+
+    def open(self):                      # io_open, m_io.F90:60-71
+        self.il = 0
+
+    def line(self, case: Optional[str] = None) -> str:
+        """io_line, m_io.F90:140-170: next non-empty line, comments (# !) cut, lower-cased unless case='C'"""
+        while True:
+            if self.il >= len(self.raw):
+                return "#"
+            ln = self.raw[self.il][:300]
+            self.il += 1
+            ln = ln.lstrip(" ")
+            m = re.search(r"[#!]", ln)
+            if m:
+                ln = ln[:m.start()]
+            ln = ln.rstrip()
+            if case is None or case in "Ll":
+                ln = ln.lower()
+            elif case in "Uu":
+                ln = ln.upper()
+            if ln.strip():
+                return ln
+
+    def step(self, keyword: str, case: str = "L", part: str = "S") -> str:
+        """io_step, m_io.F90:172-234"""
+        in_block, old_il, reopen = 0, self.il, False
+        while True:
+            ln = self.line(case=case)
+            lline = ln.lower()
+            if in_block == 0 and io_part(ln, keyword, part):
+                return ln
+            if reopen and old_il <= self.il:
+                return "#"
+            if lline.startswith("begin"):
+                in_block += 1
+            if lline.startswith("end") and in_block > 0:
+                in_block -= 1
+            if ln[:1] == "#":
+                self.open()
+                reopen = True
+
+
+def has_sub(s: str, sub: str, word: bool = False) -> bool:
+    """m_io.F90:95-113 (strings behave as blank-padded Fortran characters)"""
+    if word:
+        padded = s + " "
+        if (" " + sub.strip() + " ") in padded:
+            return True
+        return (sub.strip() + " ") in padded
+    return sub in s
+
+
+def strip(s: str, n: int = 1) -> str:
+    """m_io.F90:115-132: drop the first n blank-delimited words"""
+    for _ in range(n):
+        i = s.find(" ")
+        s = s[i + 1:].lstrip(" ") if i >= 0 else ""
+    return s
+
+
+def io_part(line: str, keyword: str, part: str = "S") -> bool:
+    """m_io.F90:236-288"""
+    part = part.upper()
+    lline = line.lower()
+    if part == "S":
+        return line.startswith(keyword)
+    if part == "P":
+        return has_sub(line, keyword)
+    if part == "B":
+        return lline.startswith("begin") and has_sub(line, keyword, word=True)
+    if part == "C":
+        return lline.startswith("begin") and has_sub(line, keyword)
+    if part == "K":
+        return line.startswith(keyword) or (lline.startswith("begin") and has_sub(line, keyword, word=True))
+    if part == "O":
+        return has_sub(line, keyword)
+    return False
+
+
+def _reals(s: str, n: int) -> List[float]:
+    toks = re.split(r"[\s,]+", s.strip())
+    return [float(t.replace("d", "e")) for t in toks[:n]]
+
+
+def _next_real(s: str) -> float:         # m_mg_io.F90:408-413
+    return _reals(strip(s), 1)[0]
+
+
+def _next_int(s: str) -> Tuple[int, str]:   # m_mg_io.F90:415-420
+    s = strip(s)
+    return int(re.split(r"[\s,]+", s.strip())[0]), s
+
+
+def iomg_read(IO: MgIO, dtype=np.float64, default_steps: int = 2, echo=None) -> G.MgGrid:
+    """m_mg_io.F90:48-406.  Returns the top grid with its children, BCs and boxes.
+
+    `default_steps`: the reference leaves `steps` uninitialised when no `v-steps` line is given
+    (m_mg_io.F90:67,173-174); here that case is defined as 2, the library default (t_mg.f90:93).
+    """
+    say = echo if echo is not None else (lambda *_: None)
+    grid = G.MgGrid(dtype)
+    IO.open()
+    offset = np.zeros(3)
+    cell = np.zeros((3, 3))
+    st = dict(sor=1.8, tol=1.0e-4, nnn=[0, 0, 0], steps=default_steps, restrict=G.MG_INTERP_FULL,
+              prolong=G.MG_INTERP_FULL, BC=np.full((2, 3), G.MG_BC_DIRICHLET, dtype=np.int64))
+    N_layers, N_boxes = 1000, 10
+
+    line = IO.step("length")
+    if line[:1] != "#":
+        line = strip(line)
+        if line.startswith("ang"):
+            conv = G.ANG
+        elif line.startswith("bohr"):
+            conv = 1.0
+        elif line.startswith("nm"):
+            conv = 10.0 * G.ANG
+        else:
+            raise G.MgStop("Could not decipher the length unit [Ang|Bohr|nm]")
+    else:
+        conv = G.ANG
+
+    line = IO.step("offset")
+    if line[:1] != "#":
+        offset = np.array(_reals(strip(line), 3)) * conv
+
+    line = IO.step("cell", part="K")
+    if line[:1] != "#":
+        if io_part(line, "begin"):
+            for i in range(3):
+                cell[:, i] = _reals(IO.line(), 3)
+        else:
+            v = _reals(strip(line), 3)
+            cell[0, 0], cell[1, 1], cell[2, 2] = v
+        cell = cell * conv
+
+    line = IO.step("max-layers")
+    if line[:1] != "#":
+        N_layers = int(_reals(strip(line), 1)[0])
+    line = IO.step("boxes")
+    if line[:1] != "#":
+        N_boxes = int(_reals(strip(line), 1)[0])
+
+    w_pref = 0
+    line = IO.step("weight")
+    if line[:1] != "#":
+        line = strip(line)
+        if has_sub(line, "equal", word=True):
+            w_pref = 0
+        elif has_sub(line, "short", word=True):
+            w_pref = 1
+        elif has_sub(line, "long", word=True):
+            w_pref = -1
+
+    def populate_layer_info():
+        """m_mg_io.F90:272-351"""
+        line = IO.line()
+        while not has_sub(line, "end"):
+            if line.startswith("sor"):
+                st["sor"] = _next_real(line)
+            elif line.startswith("tol"):
+                st["tol"] = _next_real(line)
+            elif line.startswith("nnn") or line.startswith("size") or line.startswith("mesh-size"):
+                for k in range(3):
+                    st["nnn"][k], line = _next_int(line)
+            elif line.startswith("v-steps"):
+                st["steps"], line = _next_int(line)
+            elif line.startswith("bc") or line.startswith("boundary-condition"):
+                line = strip(line)
+                opt = strip(line)
+                lBC = None
+                if opt.startswith("periodic"):
+                    lBC = G.MG_BC_PERIODIC
+                elif opt.startswith("dirichlet"):
+                    lBC = G.MG_BC_DIRICHLET
+                elif opt.startswith("neumann"):
+                    lBC = G.MG_BC_NEUMANN
+                if lBC is not None:
+                    if line.startswith("all"):
+                        st["BC"][:, :] = lBC
+                    else:
+                        if has_sub(line, "+"):
+                            mask = (False, True)
+                        elif has_sub(line, "-"):
+                            mask = (True, False)
+                        else:
+                            mask = (True, True)
+                        j = {"a": 0, "b": 1, "c": 2}.get(line[:1])
+                        if j is not None:
+                            for k in range(2):
+                                if mask[k]:
+                                    st["BC"][k, j] = lBC
+            elif line.startswith("interp"):
+                line = strip(line)
+                if line.startswith("half"):
+                    st["restrict"] = st["prolong"] = G.MG_INTERP_HALF
+                if line.startswith("full"):
+                    st["restrict"] = st["prolong"] = G.MG_INTERP_FULL
+            elif line.startswith("restrict"):
+                line = strip(line)
+                if line.startswith("half"):
+                    st["restrict"] = G.MG_INTERP_HALF
+                if line.startswith("full"):
+                    st["restrict"] = G.MG_INTERP_FULL
+            elif line.startswith("prolong"):
+                line = strip(line)
+                if line.startswith("half"):
+                    st["prolong"] = G.MG_INTERP_HALF
+                if line.startswith("full"):
+                    st["prolong"] = G.MG_INTERP_FULL
+            line = IO.line()
+
+    def apply_bc():
+        for k, j, plane in ((0, 0, G.MG_BC_A0), (1, 0, G.MG_BC_A1), (0, 1, G.MG_BC_B0), (1, 1, G.MG_BC_B1),
+                            (0, 2, G.MG_BC_C0), (1, 2, G.MG_BC_C1)):
+            G.grid_BC(grid, int(st["BC"][k, j]), plane)
+
+    line = IO.step("layers", part="B")
+    if line[:1] == "#":
+        say("Could not read generic layer information")
+        say("This information is necessary!")
+        raise G.MgStop("")
+    say("Reading generic layer information")
+    populate_layer_info()
+    G.init_grid(grid, st["nnn"], cell, N_boxes, tol=st["tol"], offset=offset, sor=st["sor"], steps=st["steps"])
+    G.init_grid_children_half(grid, max_layer=N_layers)
+    N_layers = G.layers(grid)
+    apply_bc()
+    for i_layer in range(1, N_layers + 1):
+        G.grid_set(grid, layer=i_layer, weight=w_pref, restrict=st["restrict"], prolong=st["prolong"])
+
+    st["BC"][:, :] = -1
+    line = IO.step("layer", part="B")
+    i = IO.il
+    more = True
+    while more:
+        line = IO.step("layer", part="B")
+        if IO.il == i:
+            more = False
+        if line[:1] != "#":
+            i_layer = int(_reals(strip(strip(line)), 1)[0])
+            if i_layer < 0:
+                i_layer = G.layers(grid) + i_layer + 1
+            elif i_layer == 0:
+                raise G.MgStop("The 0th layer is not existing, i < 0 < i, only!")
+            if 0 < i_layer <= G.layers(grid):
+                say(f"Reading layer {i_layer} information")
+                g = G.grid_layer(grid, i_layer)
+                populate_layer_info()
+                G.grid_set(g, tol=st["tol"], sor=st["sor"], steps=st["steps"], restrict=st["restrict"],
+                           prolong=st["prolong"])
+                apply_bc()
+
+    i_box = 0
+    line = IO.step("box", part="B")
+    i = IO.il
+    more = True
+    while more:
+        line = IO.step("box", part="B")
+        if IO.il == i:
+            more = False
+        if line[:1] != "#":
+            i_box += 1
+            say(f"Reading box {i_box} information")
+            # populate_box_info, m_mg_io.F90:353-404
+            bcell = np.zeros((3, 3))
+            llc = np.zeros(3)
+            value, rho, constant = 0.0, 1.0, True
+            line = IO.line()
+            while not has_sub(line, "end"):
+                if line.startswith("llc") or line.startswith("lower-left-corner"):
+                    llc = np.array(_reals(strip(line), 3))
+                elif line.startswith("cell"):
+                    v = _reals(strip(line), 3)
+                    bcell[0, 0], bcell[1, 1], bcell[2, 2] = v
+                elif has_sub(line, "cell"):
+                    for k in range(3):
+                        bcell[:, k] = _reals(IO.line(), 3)
+                    line = IO.line()
+                elif line.startswith("val"):
+                    value = _next_real(line)
+                elif line.startswith("density") or line.startswith("rho"):
+                    rho = _next_real(line)
+                elif line.startswith("constant"):
+                    line = strip(line)
+                    if line.startswith("t"):
+                        constant = True
+                    elif line.startswith("f"):
+                        constant = False
+                    else:
+                        say("Warning: Read constant value, could not be true/t/false/f")
+                line = IO.line()
+            G.grid_add_box(grid, llc * conv, bcell * conv, value, rho, constant)
+    return grid
+
+
+def read_method(IO: MgIO) -> int:
+    """the `method` line of src/mg.F90:75-85: 1 bottom-up (default), 2 "W"/v-cycle"""
+    IO.open()
+    line = IO.step("method")
+    if line[:1] != "#":
+        line = strip(line)
+        if "v" in line or "w" in line:      # has_sub(line,'v-cycle') .or. has_sub(line,'v') .or. has_sub(line,'w') ...
+            return 2
+        if "bottom-up" in line or "bu" in line:
+            return 1
+    return 1
+
+
+def save_names(IO: MgIO, keyword: str = "save") -> List[str]:
+    """file names of the `save` / `init-save` lines (src/mg.F90:91-131), case preserved"""
+    IO.open()
+    out = []
+    line = IO.step(keyword, case="C")
+    if line[:1] == "#":
+        return out
+    first = None
+    while first != IO.il:
+        if first is None:
+            first = IO.il
+        if line[:1] != "#":
+            out.append(strip(line).strip())
+        line = IO.step(keyword, case="C")
+    return out
+
+
+# ------------------------------------------------------------------------------------------------
+# .VMG container (src/m_mg_save.F90:231-267): Fortran sequential unformatted, 4-byte record markers
+
+def _rec(f, payload: bytes):
+    f.write(struct.pack("<i", len(payload)))
+    f.write(payload)
+    f.write(struct.pack("<i", len(payload)))
+
+
+def write_vmg(path: str, grid: G.MgGrid, V: np.ndarray) -> None:
+    """V: ghosted field, shape (n3+2, n2+2, n1+2); planes z = 1..n3 with their x/y ghosts are stored"""
+    n = [int(v) for v in grid.n]
+    assert V.shape == (n[2] + 2, n[1] + 2, n[0] + 2)
+    with open(path, "wb") as f:
+        _rec(f, "Created by Nick Papior Andersens multigrid-method".ljust(200).encode())
+        _rec(f, np.array(n, dtype="<i4").tobytes())
+        _rec(f, np.asarray(grid.offset, dtype="<f8").tobytes())
+        _rec(f, np.asarray(grid.cell, dtype="<f8").T.tobytes())     # Fortran cell(3,3), column major
+        for z in range(1, n[2] + 1):
+            _rec(f, np.ascontiguousarray(V[z]).tobytes())
+
+
+def read_vmg(path: str, dtype):
+    raw = open(path, "rb").read()
+    off = 0
+
+    def rec():
+        nonlocal off
+        ln = struct.unpack_from("<i", raw, off)[0]
+        data = raw[off + 4: off + 4 + ln]
+        if struct.unpack_from("<i", raw, off + 4 + ln)[0] != ln:
+            raise ValueError("corrupt record markers")
+        off += 8 + ln
+        return data
+    rec()
+    n = np.frombuffer(rec(), "<i4")
+    offset = np.frombuffer(rec(), "<f8")
+    cell = np.frombuffer(rec(), "<f8").reshape(3, 3).T
+    planes = [np.frombuffer(rec(), dtype).reshape(n[1] + 2, n[0] + 2) for _ in range(n[2])]
+    return n, offset, cell, np.stack(planes)
+
+
+def vmg_name(filename: str) -> str:
+    """mg_save (m_mg_save.F90:35-84) strips the extension and mg_binary appends '.VMG'"""
+    i = filename.find(".")
+    return (filename[:i] if i > 0 else filename) + ".VMG"

@@ -33,3 +33,15 @@ def bits_equal(a, b):
     assert a.dtype == b.dtype and a.shape == b.shape, (a.dtype, b.dtype, a.shape, b.shape)
     iv = np.uint32 if a.dtype == np.float32 else np.uint64
     return np.array_equal(a.view(iv), b.view(iv))
+
+
+def oracle_levels(top):
+    """oracle Level list from a multigrid_amd.grid.MgGrid hierarchy"""
+    out = []
+    for g in top.levels():
+        out.append(orc.Level(
+            n=tuple(int(v) for v in g.n), bc=tuple(g.bc6()), sor=float(g.sor), a=tuple(float(v) for v in g.a),
+            tol=float(g.tol), steps=int(g.steps), res_method=int(g.RES_method), pro_method=int(g.PRO_method),
+            boxes=[orc.Box(tuple(int(max(-2**31, min(2**31 - 1, v))) for v in b.place), float(b.val), float(b.rho),
+                           bool(b.constant)) for b in g.box]))
+    return out
