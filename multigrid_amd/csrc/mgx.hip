@@ -5,6 +5,7 @@
 #include <cmath>
 #include <cstdarg>
 #include <cstdio>
+#include <cstdlib>
 #include <cstring>
 #include <string>
 #include <vector>
@@ -114,6 +115,7 @@ extern "C" int mgx_ctx_create(int device, void *stream, mgx_ctx **out) {
                 prop.gcnArchName);
   mgx_ctx *c = new mgx_ctx();
   c->device = device;
+  if (const char *e = getenv("MGX_FUSED_TY")) mgx_fused_ty = atoi(e);   // tile-height override for benchmarking
   if (stream) {
     c->stream = (hipStream_t)stream;
   } else {
@@ -129,10 +131,10 @@ extern "C" int mgx_ctx_create(int device, void *stream, mgx_ctx **out) {
 
 extern "C" int mgx_ctx_destroy(mgx_ctx *ctx) {
   if (!ctx) return MGX_OK;
-  hipSetDevice(ctx->device);
-  hipStreamSynchronize(ctx->stream);
-  if (ctx->own_stream) hipStreamDestroy(ctx->stream);
-  if (ctx->h_res) hipHostFree(ctx->h_res);
+  (void)hipSetDevice(ctx->device);
+  (void)hipStreamSynchronize(ctx->stream);
+  if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
+  if (ctx->h_res) (void)hipHostFree(ctx->h_res);
   delete ctx;
   return MGX_OK;
 }
@@ -180,13 +182,13 @@ extern "C" int mgx_level_create_slab(mgx_ctx *ctx, int layer, const int32_t n[3]
   for (int i = 0; i < 2; ++i) {
     hipError_t e = hipMalloc(&lv->buf[i], bytes);
     if (e != hipSuccess) {
-      if (i) hipFree(lv->buf[0]);
+      if (i) (void)hipFree(lv->buf[0]);
       delete lv;
       return fail(MGX_ENOMEM, "mgx_level_create: hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
     }
   }
   hipError_t e = hipMalloc((void **)&lv->d_res, MGX_RES_WORDS * sizeof(u64));
-  if (e != hipSuccess) { hipFree(lv->buf[0]); hipFree(lv->buf[1]); delete lv; return fail(MGX_ENOMEM, "hipMalloc(result)"); }
+  if (e != hipSuccess) { (void)hipFree(lv->buf[0]); (void)hipFree(lv->buf[1]); delete lv; return fail(MGX_ENOMEM, "hipMalloc(result)"); }
   HIP_TRY(hipMemsetAsync(lv->buf[0], 0, bytes, ctx->stream));
   HIP_TRY(hipMemsetAsync(lv->buf[1], 0, bytes, ctx->stream));
   HIP_TRY(hipMemsetAsync(lv->d_res, 0, MGX_RES_WORDS * sizeof(u64), ctx->stream));
@@ -203,12 +205,12 @@ extern "C" int mgx_level_create(mgx_ctx *ctx, int layer, const int32_t n[3], int
 
 extern "C" int mgx_level_destroy(mgx_level *lv) {
   if (!lv) return MGX_OK;
-  hipSetDevice(lv->ctx->device);
-  hipStreamSynchronize(lv->ctx->stream);
-  hipFree(lv->buf[0]);
-  hipFree(lv->buf[1]);
-  hipFree(lv->d_res);
-  if (lv->d_boxes) hipFree(lv->d_boxes);
+  (void)hipSetDevice(lv->ctx->device);
+  (void)hipStreamSynchronize(lv->ctx->stream);
+  (void)hipFree(lv->buf[0]);
+  (void)hipFree(lv->buf[1]);
+  (void)hipFree(lv->d_res);
+  if (lv->d_boxes) (void)hipFree(lv->d_boxes);
   delete lv;
   return MGX_OK;
 }
@@ -363,16 +365,17 @@ template <typename T>
 static int do_sweeps(mgx_level *lv, int nsweeps, int reduce) {
   const MgxGeom &g = lv->g;
   int which = C(lv)->kernel;
-  if (which == MGX_KERNEL_AUTO) which = mgx_fused_supported<T>(g) ? MGX_KERNEL_FUSED : MGX_KERNEL_TWO_PASS;
-  if (which == MGX_KERNEL_FUSED && !mgx_fused_supported<T>(g))
-    return fail(MGX_ELIMIT, "mgx_level_sweep: fused kernel does not support this level shape");
+  if (which == MGX_KERNEL_AUTO) which = mgx_fused_supported<T>(g, lv->nbox) ? MGX_KERNEL_FUSED : MGX_KERNEL_TWO_PASS;
+  if (which == MGX_KERNEL_FUSED && !mgx_fused_supported<T>(g, lv->nbox))
+    return fail(MGX_ELIMIT, "mgx_level_sweep: the fused kernel handles at most %d boxes", MGX_MAX_FUSED_BOXES);
   for (int s = 0; s < nsweeps; ++s) {
     const int red = (s == nsweeps - 1) ? reduce : 0;
     if (red) TRY(reset_result(lv));
     if (which == MGX_KERNEL_FUSED) {
       TRY(sync_shell<T>(lv));
-      TRY((mgx_fused_launch<T>((const T *)lv->buf[lv->cur], (T *)lv->buf[1 - lv->cur], g, make_params<T>(lv),
-                               lv->d_boxes, lv->nbox, red, lv->d_res, C(lv)->stream)));
+      if (mgx_fused_launch<T>((const T *)lv->buf[lv->cur], (T *)lv->buf[1 - lv->cur], g, make_params<T>(lv),
+                              lv->d_boxes, lv->nbox, red, lv->d_res, C(lv)->stream) != 0)
+        return fail(MGX_EHIP, "mgx_level_sweep: fused kernel launch configuration failed");
       HIP_TRY(hipGetLastError());
       lv->cur = 1 - lv->cur;
     } else {
@@ -545,7 +548,7 @@ static int g2g(int n1, int i1, int n2) {                 // t_mg_interp.f90:995-
 
 struct DevTable {
   int *d = nullptr;
-  ~DevTable() { if (d) hipFree(d); }
+  ~DevTable() { if (d) (void)hipFree(d); }
 };
 
 static int upload_table(const std::vector<int> &h, DevTable &t, hipStream_t st) {

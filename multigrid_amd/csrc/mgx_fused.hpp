@@ -1,11 +1,381 @@
-// Fused black+red sweep (one read and one write of the field per full sweep).
+// Fused red-black sweep: black (odd x+y+z) and red (even) half-sweeps of gs (m_gs_CDS.F90:317-345)
+// in ONE pass over the field, out of place (src -> dst), so that a full sweep costs one read and
+// one write of every cell.
+//
+// Work decomposition.  A block owns an output tile of 128 x TY cells (64 x-pairs: a pair is one odd
+// and one even cell, 16 bytes in fp64, so every global access is a 16-byte lane access and a wave
+// row is 1 KiB contiguous, 128-byte aligned) and marches ZC planes in z.  The block stages TY+4 rows
+// (two halo rows each side) of 66 pairs (one halo pair each side).  Waves 0-3 own whole rows
+// (lane = pair, rows w, w+4, ...); wave 4 owns the halo pairs of every row.  Every lane keeps the
+// z-column of each of its pairs in registers (planes k-1, k, k+1 plus the plane k+2 in flight and
+// the black value of plane k-2), so only in-plane neighbours go through LDS.
+//
+// Per plane k:
+//   black(k)  on the tile grown by one cell (the ring is recomputed redundantly by neighbouring
+//             tiles; only the owner counts it in the reductions); new values go to registers + LDS
+//   barrier
+//   red(k-1)  on the tile proper: it now sees new black values on planes k-2, k-1, k; the finished
+//             pair is stored to dst
+//   stage     raw plane k+1 into LDS for the next step; rotate the register window
+//   barrier
+// LDS holds three plane slots (k-1: black-updated, k: being updated, k+1: incoming), colour-split
+// (component 0 / component 1 of the pairs in separate arrays) so that 8-byte reads of consecutive
+// lanes are bank-conflict free.  Ghost cells are never written: dst must already hold src's shell.
+//
+// Boxes (t_mg.f90:634-710).  A tile no box reaches runs a body without any box logic (weights
+// a(dir)/sum, precomputed on the host with the reference's arithmetic).  Other tiles use bit sets
+// over the (at most 32) boxes: in_box(b,x,y,z) = X_b(x) & Y_b(y) & Z_b(z); the X and Y sets of a lane's
+// pairs are constant along z and live in registers, the Z sets of planes k-1, k, k+1 are made by
+// wave 4 with a ballot per step.  "any constant box" = set & constant-mask, "first box" = lowest
+// set bit, exactly the reference's scans.
 #pragma once
 
-#include "mgx_common.hpp"
+#include "mgx_kernels.hpp"
+
+template <typename T> struct MgxVec2;
+template <> struct MgxVec2<double> { typedef double2 type; };
+template <> struct MgxVec2<float> { typedef float2 type; };
+
+// item flags (constant along z)
+#define MGX_F_LOAD 1      // pair exists in memory: stage it
+#define MGX_F_BLK0 2      // the component-0 cell may be updated when it is black
+#define MGX_F_BLK1 4      // same for component 1
+#define MGX_F_RED0 8      // component-0 cell may be updated when it is red (tile proper only)
+#define MGX_F_RED1 16
+#define MGX_F_STORE 32    // pair is stored to dst with the red plane
+#define MGX_F_OWN0 64     // component 0 counts in this tile's reductions
+#define MGX_F_OWN1 128
+
+#define MGX_MAX_FUSED_BOXES 32
 
 template <typename T>
-static bool mgx_fused_supported(const MgxGeom &) { return false; }
+struct MgxBoxLds {           // per-block copy of what the box body needs
+  unsigned zsets[2][4];      // [step parity][plane k-1, k, k+1, unused]
+  T rho[MGX_MAX_FUSED_BOXES + 1];   // rho of box b; slot 32 = 1 (no box)
+};
+
+// new value of one cell in a tile that boxes reach.  sets: boxes containing the cell (c) and its six
+// neighbours; cmask: constant boxes; rmask: boxes with rho != 1.
+template <typename T>
+__device__ inline T mgx_cell_new_sets(const T vc, const T vxm, const T vxp, const T vym, const T vyp, const T vzm,
+                                      const T vzp, const unsigned sc, const unsigned sxm, const unsigned sxp,
+                                      const unsigned sym, const unsigned syp, const unsigned szm, const unsigned szp,
+                                      const unsigned cmask, const unsigned rmask, const T *__restrict__ rho,
+                                      const MgxSweepParams<T> &p) {
+  T avg;
+  if (sc & cmask) {
+    avg = vc;                                            // val returns V itself (m_gs_CDS.F90:726-727)
+  } else {
+    // first containing box decides rho (t_mg.f90:670-687); lowest set bit = first box
+    const unsigned fx = sxm & (0u - sxm), fxp = sxp & (0u - sxp), fy = sym & (0u - sym), fyp = syp & (0u - syp),
+                   fz = szm & (0u - szm), fzp = szp & (0u - szp);
+    if (((fx | fxp | fy | fyp | fz | fzp) & rmask) == 0) {
+      avg = mgx_avg_uniform<T>(vxm, vxp, vym, vyp, vzm, vzp, p.w);
+    } else {
+      T r[6];
+      r[0] = rho[sxm ? __ffs((int)sxm) - 1 : 32] * p.a[0];
+      r[1] = rho[sxp ? __ffs((int)sxp) - 1 : 32] * p.a[0];
+      r[2] = rho[sym ? __ffs((int)sym) - 1 : 32] * p.a[1];
+      r[3] = rho[syp ? __ffs((int)syp) - 1 : 32] * p.a[1];
+      r[4] = rho[szm ? __ffs((int)szm) - 1 : 32] * p.a[2];
+      r[5] = rho[szp ? __ffs((int)szp) - 1 : 32] * p.a[2];
+      T s = r[0];
+      s = s + r[1]; s = s + r[2]; s = s + r[3]; s = s + r[4]; s = s + r[5];
+#pragma unroll
+      for (int i = 0; i < 6; ++i) r[i] = r[i] / s;
+      avg = vxm * r[0] + vxp * r[1];
+      avg = avg + vym * r[2];
+      avg = avg + vyp * r[3];
+      avg = avg + vzm * r[4];
+      avg = avg + vzp * r[5];
+    }
+  }
+  return p.s1 * vc + p.s2 * avg;
+}
+
+template <typename T, int TY, bool BOXES>
+__device__ inline void mgx_fused_body(const T *__restrict__ src, T *__restrict__ dst, const MgxGeom &g,
+                                      const MgxSweepParams<T> &p, const MgxBox *__restrict__ bx, const int nb,
+                                      const int tx0, const int ty0, const int zc0, const int zc1, const int reduce,
+                                      u64 *__restrict__ res, T *__restrict__ lds, MgxBoxLds<T> *__restrict__ bl) {
+  typedef typename MgxVec2<T>::type V2;
+  constexpr int TXP = 64;
+  constexpr int LP = TXP + 2;            // pairs per staged row
+  constexpr int LR = TY + 4;             // staged rows
+  constexpr int PL = LP * LR;            // pairs per staged plane
+  constexpr int R = LR / 4;              // rows per row-wave
+  static_assert(LR % 4 == 0, "staged rows must divide over four waves");
+  static_assert(2 * LR <= 64, "halo pairs must fit one wave");
+  auto L = [&](int slot, int comp, int li) -> T & { return lds[(slot * 2 + comp) * PL + li]; };
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+
+  // ---- items of this lane ----
+  int li[R], fl[R], iy[R], ixs[R];
+  long long go[R];
+  unsigned mx[R][4], my[R][3];           // BOXES: boxes whose x range holds xs-1..xs+2 / y range holds y-1..y+1
+#pragma unroll
+  for (int j = 0; j < R; ++j) {
+    int r, pc;
+    bool valid;
+    if (wave < 4) { r = wave + 4 * j; pc = lane + 1; valid = true; }
+    else { r = lane >> 1; pc = (lane & 1) ? LP - 1 : 0; valid = (j == 0) && lane < 2 * LR; }
+    const int y = ty0 - 2 + r, xs = tx0 - 2 + 2 * pc;
+    const bool halo = (pc == 0 || pc == LP - 1);
+    int f = 0;
+    if (valid && y >= 0 && y <= g.n2 + 1 && xs <= g.n1 + 1) {
+      f |= MGX_F_LOAD;
+      const bool yb = r >= 1 && r <= LR - 2 && y >= 1 && y <= g.n2;       // black rows: tile grown by one
+      const bool yr = r >= 2 && r <= LR - 3 && y >= 1 && y <= g.n2;       // red rows: tile proper
+      const bool x0ok = xs >= 1 && xs <= g.n1, x1ok = xs + 1 >= 1 && xs + 1 <= g.n1;
+      if (yb && x0ok && (!halo || pc == LP - 1)) f |= MGX_F_BLK0;         // right halo: only its first cell
+      if (yb && x1ok && (!halo || pc == 0)) f |= MGX_F_BLK1;              // left halo: only its second cell
+      if (yr && !halo) {
+        if (x0ok) f |= MGX_F_RED0 | MGX_F_OWN0;
+        if (x1ok) f |= MGX_F_RED1 | MGX_F_OWN1;
+        if (x0ok) f |= MGX_F_STORE;
+      }
+    }
+    li[j] = r * LP + pc;
+    fl[j] = f;
+    iy[j] = y;
+    ixs[j] = xs;
+    // pairs that do not exist are fetched from a harmless address instead of being predicated, so that no
+    // branch (and no wait) sits between a load and its first use
+    go[j] = (f & MGX_F_LOAD) ? g.front + (long long)(xs - 1) + (long long)g.px * y : g.front;
+    if (BOXES) {
+#pragma unroll
+      for (int d = 0; d < 4; ++d) mx[j][d] = 0u;
+#pragma unroll
+      for (int d = 0; d < 3; ++d) my[j][d] = 0u;
+      for (int b = 0; b < nb; ++b) {
+        const int l0 = bx[b].lo[0], h0 = bx[b].hi[0], l1 = bx[b].lo[1], h1 = bx[b].hi[1];
+#pragma unroll
+        for (int d = 0; d < 4; ++d) mx[j][d] |= (l0 <= xs - 1 + d && xs - 1 + d <= h0) ? (1u << b) : 0u;
+#pragma unroll
+        for (int d = 0; d < 3; ++d) my[j][d] |= (l1 <= y - 1 + d && y - 1 + d <= h1) ? (1u << b) : 0u;
+      }
+    }
+  }
+  unsigned cmask = 0u, rmask = 0u;
+  int blo2 = 1, bhi2 = 0;                // z range of "my" box (wave 4: lane = box)
+  if (BOXES) {
+    for (int b = 0; b < nb; ++b) {
+      cmask |= bx[b].constant ? (1u << b) : 0u;
+      rmask |= bx[b].rho_is_one ? 0u : (1u << b);
+    }
+    if (wave == 4 && lane < nb) { blo2 = bx[lane].lo[2]; bhi2 = bx[lane].hi[2]; }
+    if (threadIdx.x <= MGX_MAX_FUSED_BOXES) bl->rho[threadIdx.x] = threadIdx.x < nb ? (T)bx[threadIdx.x].rho : (T)1;
+  }
+  // Z sets for planes zz-1, zz, zz+1 (global), written by wave 4 into parity slot `par`
+  auto make_zsets = [&](int zz, int par) {
+    if (BOXES && wave == 4) {
+#pragma unroll
+      for (int d = 0; d < 3; ++d) {
+        const unsigned long long m = __ballot(blo2 <= zz - 1 + d && zz - 1 + d <= bhi2);
+        if (lane == 0) bl->zsets[par][d] = (unsigned)m;
+      }
+    }
+  };
+  const long long pzl = g.pz;
+
+  // register window of every pair: planes k-1 (m*), k (c*), k+1 (n*), k+2 in flight (i*); component 0 / 1
+  // kept as separate scalars so that the colour select is a value select, never an address select
+  T m0[R], m1[R], c0[R], c1[R], n0[R], n1[R], i0[R], i1[R], below[R];
+#define MGX_FETCH(z, a0, a1)                                                           \
+  {                                                                                    \
+    const long long pb_ = pzl * ((z) + 1);                                             \
+    _Pragma("unroll") for (int j = 0; j < R; ++j) {                                    \
+      const V2 t_ = *reinterpret_cast<const V2 *>(src + pb_ + go[j]);                  \
+      a0[j] = t_.x; a1[j] = t_.y;                                                      \
+    }                                                                                  \
+  }
+#define MGX_STAGE(slot, a0, a1)                                                        \
+  {                                                                                    \
+    _Pragma("unroll") for (int j = 0; j < R; ++j)                                      \
+      if (fl[j] & MGX_F_LOAD) { L(slot, 0, li[j]) = a0[j]; L(slot, 1, li[j]) = a1[j]; } \
+  }
+#pragma unroll
+  for (int j = 0; j < R; ++j) { i0[j] = i1[j] = below[j] = (T)0; }
+  MGX_FETCH(zc0 - 2, m0, m1)
+  MGX_FETCH(zc0 - 1, c0, c1)
+  MGX_FETCH(zc0, n0, n1)
+  int sk = 0;                      // LDS slot of plane k; k-1 lives in sk-1, k+1 in sk+1 (mod 3)
+  MGX_STAGE(sk, c0, c1)
+  make_zsets(zc0 - 1 + g.z0, (zc0 - 1) & 1);
+  __syncthreads();
+
+  T err = (T)0;
+  u64 slo = 0, shi = 0;
+  unsigned ovf = 0;
+  unsigned zmm = 0u;               // Z set of plane k-2
+
+  for (int k = zc0 - 1; k <= zc1 + 1; ++k) {
+    const int zg = k + g.z0;
+    const int sm = sk == 0 ? 2 : sk - 1, sp = sk == 2 ? 0 : sk + 1;
+    if (k + 2 <= zc1 + 2) MGX_FETCH(k + 2, i0, i1)
+    unsigned zm = 0u, z0s = 0u, zp = 0u;
+    if (BOXES) { zm = bl->zsets[k & 1][0]; z0s = bl->zsets[k & 1][1]; zp = bl->zsets[k & 1][2]; }
+
+    // ---------------- black cells of plane k ----------------
+    if (zg >= 1 && zg <= g.n3g) {
+      const bool zown = k >= zc0 && k <= zc1;
+#pragma unroll
+      for (int j = 0; j < R; ++j) {
+        const int q = (iy[j] + zg) & 1;                     // component holding the odd cell (pairs start at odd x)
+        if (fl[j] & (q ? MGX_F_BLK1 : MGX_F_BLK0)) {
+          const T vc = q ? c1[j] : c0[j];
+          const T partner = q ? c0[j] : c1[j];
+          const T other = L(sk, 1 - q, li[j] + (2 * q - 1));
+          const T vym = L(sk, q, li[j] - LP), vyp = L(sk, q, li[j] + LP);
+          const T vzm = q ? m1[j] : m0[j], vzp = q ? n1[j] : n0[j];
+          T vv;
+          if (BOXES) {
+            const unsigned X0 = q ? mx[j][2] : mx[j][1], Xm = q ? mx[j][1] : mx[j][0], Xp = q ? mx[j][3] : mx[j][2];
+            const unsigned XY = X0 & my[j][1];
+            vv = mgx_cell_new_sets<T>(vc, q ? partner : other, q ? other : partner, vym, vyp, vzm, vzp, XY & z0s,
+                                      Xm & my[j][1] & z0s, Xp & my[j][1] & z0s, X0 & my[j][0] & z0s,
+                                      X0 & my[j][2] & z0s, XY & zm, XY & zp, cmask, rmask, bl->rho, p);
+          } else {
+            vv = p.s1 * vc + p.s2 * mgx_avg_uniform<T>(q ? partner : other, q ? other : partner, vym, vyp, vzm, vzp, p.w);
+          }
+          c0[j] = q ? c0[j] : vv;
+          c1[j] = q ? vv : c1[j];
+          L(sk, q, li[j]) = vv;
+          if (zown && (fl[j] & (q ? MGX_F_OWN1 : MGX_F_OWN0))) {
+            const T d = vv - vc;
+            const T d2 = d * d;
+            err = d2 > err ? d2 : err;
+            if (reduce & 2) mgx_exact_add(slo, shi, (double)(vv < (T)0 ? -vv : vv), ovf);
+          }
+        }
+      }
+    }
+    make_zsets(zg + 1, (k + 1) & 1);                        // for the next step; this step reads the other parity
+    __syncthreads();
+
+    // ---------------- red cells of plane k-1; store the finished plane ----------------
+    if (k - 1 >= zc0) {
+      const int kr = k - 1, zgr = kr + g.z0;
+      const long long pb = pzl * (kr + 1);
+#pragma unroll
+      for (int j = 0; j < R; ++j) {
+        const int q = (1 + iy[j] + zgr) & 1;                // component holding the even cell
+        if (fl[j] & MGX_F_STORE) {
+          if (fl[j] & (q ? MGX_F_RED1 : MGX_F_RED0)) {
+            const T vc = q ? m1[j] : m0[j];
+            const T partner = q ? m0[j] : m1[j];
+            const T other = L(sm, 1 - q, li[j] + (2 * q - 1));
+            const T vym = L(sm, q, li[j] - LP), vyp = L(sm, q, li[j] + LP);
+            const T vzp = q ? c1[j] : c0[j];
+            T vv;
+            if (BOXES) {
+              const unsigned X0 = q ? mx[j][2] : mx[j][1], Xm = q ? mx[j][1] : mx[j][0], Xp = q ? mx[j][3] : mx[j][2];
+              const unsigned XY = X0 & my[j][1];
+              vv = mgx_cell_new_sets<T>(vc, q ? partner : other, q ? other : partner, vym, vyp, below[j], vzp, XY & zm,
+                                        Xm & my[j][1] & zm, Xp & my[j][1] & zm, X0 & my[j][0] & zm,
+                                        X0 & my[j][2] & zm, XY & zmm, XY & z0s, cmask, rmask, bl->rho, p);
+            } else {
+              vv = p.s1 * vc + p.s2 * mgx_avg_uniform<T>(q ? partner : other, q ? other : partner, vym, vyp, below[j], vzp, p.w);
+            }
+            m0[j] = q ? m0[j] : vv;
+            m1[j] = q ? vv : m1[j];
+            const T d = vv - vc;
+            const T d2 = d * d;
+            err = d2 > err ? d2 : err;
+            if (reduce & 2) mgx_exact_add(slo, shi, (double)(vv < (T)0 ? -vv : vv), ovf);
+          }
+          V2 out;
+          out.x = m0[j]; out.y = m1[j];
+          *reinterpret_cast<V2 *>(dst + pb + go[j]) = out;
+        }
+      }
+    }
+
+    // ---------------- stage raw plane k+1, rotate the window ----------------
+    MGX_STAGE(sp, n0, n1)
+#pragma unroll
+    for (int j = 0; j < R; ++j) {
+      const int q = (iy[j] + k - 1 + g.z0) & 1;             // component of the odd (black) cell on plane k-1
+      below[j] = q ? m1[j] : m0[j];
+      m0[j] = c0[j]; m1[j] = c1[j];
+      c0[j] = n0[j]; c1[j] = n1[j];
+      n0[j] = i0[j]; n1[j] = i1[j];
+    }
+    sk = sp;
+    zmm = zm;                                               // Z set of plane k-1 = (k+1)-2 for the next red phase
+    __syncthreads();
+  }
+#undef MGX_FETCH
+#undef MGX_STAGE
+
+  if (reduce) mgx_block_commit<5>((double)err, slo, shi, ovf, reduce, res);
+}
+
+template <typename T, int TY>
+__global__ __launch_bounds__(320) void k_fused_sweep(const T *__restrict__ src, T *__restrict__ dst, const MgxGeom g,
+                                                     const MgxSweepParams<T> p, const MgxBox *__restrict__ bx,
+                                                     const int nb, const int ZC, const int ntx, const int nty,
+                                                     const int reduce, u64 *__restrict__ res) {
+  constexpr int TXP = 64;
+  extern __shared__ __align__(16) unsigned char mgx_lds_raw[];
+  T *lds = reinterpret_cast<T *>(mgx_lds_raw);          // [slot 0..2][comp 0..1][pairs of a staged plane]
+  MgxBoxLds<T> *bl = reinterpret_cast<MgxBoxLds<T> *>(lds + 3 * 2 * (TXP + 2) * (TY + 4));
+
+  // tile of this block; blocks that share an XCD (same blockIdx % 8) get consecutive tiles
+  int lid;
+  {
+    const int nblk = gridDim.x, b = blockIdx.x, xcd = b & 7, q = nblk >> 3, r = nblk & 7;
+    lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
+  }
+  const int tx = lid % ntx, ty = (lid / ntx) % nty, tz = lid / (ntx * nty);
+  const int tx0 = 1 + tx * 2 * TXP, ty0 = 1 + ty * TY;
+  const int zc0 = 1 + tz * ZC, zc1 = min(zc0 + ZC - 1, g.n3);
+
+  // does any box reach a position this tile ever asks about (cells grown by one, plus their neighbours)?
+  const int cls = mgx_classify(bx, nb, tx0 - 1, tx0 + 2 * TXP, ty0 - 1, ty0 + TY, zc0 - 1 + g.z0, zc1 + 1 + g.z0);
+  if (cls == 0) mgx_fused_body<T, TY, false>(src, dst, g, p, bx, nb, tx0, ty0, zc0, zc1, reduce, res, lds, bl);
+  else mgx_fused_body<T, TY, true>(src, dst, g, p, bx, nb, tx0, ty0, zc0, zc1, reduce, res, lds, bl);
+}
+
+// ------------------------------------------------------------------------------------------------
+// host side
+
+template <typename T, int TY>
+static int mgx_fused_launch_cfg(const T *src, T *dst, const MgxGeom &g, const MgxSweepParams<T> &p, const MgxBox *bx,
+                                int nb, int reduce, u64 *res, hipStream_t st) {
+  constexpr int TXP = 64;
+  constexpr size_t lds = (size_t)3 * 2 * (TXP + 2) * (TY + 4) * sizeof(T) + sizeof(MgxBoxLds<T>);
+  auto kern = k_fused_sweep<T, TY>;
+  if (lds > 64 * 1024 &&
+      hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+    return -1;
+  const int ntx = (g.n1 + 2 * TXP - 1) / (2 * TXP), nty = (g.n2 + TY - 1) / TY;
+  // z chunk: enough blocks to fill 256 CUs several times over, but at least 16 planes per chunk so
+  // that the four extra planes a chunk fetches stay cheap
+  int ZC = g.n3;
+  const long long per_chunk = (long long)ntx * nty;
+  while (ZC > 16 && per_chunk * ((g.n3 + ZC - 1) / ZC) < 4096) ZC = (ZC + 1) / 2;
+  const int nzc = (g.n3 + ZC - 1) / ZC;
+  const long long nblk = per_chunk * nzc;
+  if (nblk > 0x7fffffffLL) return -1;
+  hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(320), lds, st, src, dst, g, p, bx, nb, ZC, ntx, nty, reduce, res);
+  return 0;
+}
+
+// the box body keeps one bit per box in 32-bit sets
+template <typename T>
+static bool mgx_fused_supported(const MgxGeom &g, int nbox) {
+  return g.n1 >= 1 && g.n2 >= 1 && g.n3 >= 1 && nbox <= MGX_MAX_FUSED_BOXES;
+}
+
+static int mgx_fused_ty = 8;     // tile height selector (8, 12 or 16), settable for benchmarking
 
 template <typename T>
-static int mgx_fused_launch(const T *, T *, const MgxGeom &, const MgxSweepParams<T> &, const MgxBox *, int, int,
-                            u64 *, hipStream_t) { return -1; }
+static int mgx_fused_launch(const T *src, T *dst, const MgxGeom &g, const MgxSweepParams<T> &p, const MgxBox *bx,
+                            int nb, int reduce, u64 *res, hipStream_t st) {
+  switch (mgx_fused_ty) {
+    case 16: return mgx_fused_launch_cfg<T, 16>(src, dst, g, p, bx, nb, reduce, res, st);
+    case 12: return mgx_fused_launch_cfg<T, 12>(src, dst, g, p, bx, nb, reduce, res, st);
+    default: return mgx_fused_launch_cfg<T, 8>(src, dst, g, p, bx, nb, reduce, res, st);
+  }
+}
