@@ -1,0 +1,259 @@
+#!/usr/bin/env python3
+"""Benchmark of the V-cycle hot path on MI355X.
+
+One "step" = one full red-black SOR sweep (black + red half-sweeps, with the fused max-dV^2 and
+sum|V| reductions that the host convergence loop reads, m_gs_CDS.F90:200-210) of the finest level
+of the 512^3 mixed-boundary configuration, fp64, field resident in HBM.  `value` = lattice updates
+per second of the whole job (all ranks).  With --gpus N > 1 the level is z-slab decomposed, every
+rank owning a 512 x 512 x 512 slab of a 512 x 512 x (512 N) level (weak scaling): two halo planes
+per neighbour are exchanged per sweep over RCCL and the reductions are all-reduced.
+
+The JSON line also carries
+  roofline      achieved HBM GB/s of the sweep kernel (16 B per lattice update: one read + one write
+                of every cell per sweep) from HIP events on the kernel's stream, against 8 TB/s
+  cpu_baseline  the reference's own smoother (compiled from the reference sources into
+                oracle/_ref/, OpenMP) — or the C oracle if that binary is not present — timed on a
+                bounded sample on this host
+  vcycle        wall time of the complete `method v-cycle` solve of the same input to its
+                tolerance (tol 1e-8 unless --vcycle-tol), with sweep counts per level
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import subprocess
+import sys
+import tempfile
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+METRIC = "V-cycle time-to-1e-8 residual at 512³; red-black sweep GLUP/s; % HBM peak"
+HBM_PEAK_GBS = 8000.0
+BYTES_PER_LUP = 16.0          # fp64: every cell read once and written once per sweep
+
+
+def config3_input(n=(512, 512, 512), tol="1.e-8", sor="1.7", steps=2, method="v-cycle", max_layers=8) -> str:
+    """512^3 mixed Dirichlet/Neumann/periodic case in the reference's input grammar
+    (two plate electrodes +-0.5 and a rho = 3 block between them)"""
+    L = [0.1 * v for v in n]
+    def f(v):
+        return f"{v:.10g}"
+    return f"""
+cell {f(L[0])} {f(L[1])} {f(L[2])}
+max-layers {max_layers}
+boxes 4
+method {method}
+save bench.vmg
+begin layers
+  sor {sor}
+  tol {tol}
+  v-steps {steps}
+  mesh-size {n[0]} {n[1]} {n[2]}
+  bc a periodic
+  bc b periodic
+  bc c- neumann
+  bc c+ dirichlet
+  interp full
+end layers
+begin box
+  llc {f(0.4 * L[0])} {f(0.4 * L[1])} {f(0.05 * L[2])}
+  cell {f(0.2 * L[0])} {f(0.2 * L[1])} {f(0.9 * L[2])}
+  value 0.
+  rho 3.
+  constant false
+end box
+begin box
+  llc {f(0.25 * L[0])} {f(0.25 * L[1])} 0.
+  cell {f(0.5 * L[0])} {f(0.5 * L[1])} {f(0.05 * L[2])}
+  value 0.5
+end box
+begin box
+  llc {f(0.25 * L[0])} {f(0.25 * L[1])} {f(0.95 * L[2])}
+  cell {f(0.5 * L[0])} {f(0.5 * L[1])} {f(0.05 * L[2])}
+  value -0.5
+end box
+"""
+
+
+def cpu_baseline(seconds_target: float = 15.0):
+    """The reference's gs_step on this host's cores, on a bounded sample (256^3 of the same geometry)."""
+    from multigrid_amd import mgio
+    n = (256, 256, 256)
+    top = mgio.iomg_read(mgio.MgIO(text=config3_input(n)))
+    cores = max(1, min(16, os.cpu_count() or 1))
+    exe = os.path.join(ROOT, "oracle", "_ref", "ref_driver_omp_f64")
+    boxes = [b for b in top.box if not np.all(b.place == 0)]
+    if os.path.exists(exe):
+        try:
+            def run(k):
+                with tempfile.TemporaryDirectory() as td:
+                    case, out = os.path.join(td, "case.txt"), os.path.join(td, "out.bin")
+                    with open(case, "w") as fcase:
+                        fcase.write(f"5\n{n[0]} {n[1]} {n[2]}\n{' '.join(map(str, top.bc6()))}\n{top.sor!r}\n-1 -1 -1\n{len(boxes)}\n")
+                        for b in boxes:
+                            fcase.write(" ".join(str(int(v)) for v in b.place) + f" {b.val!r} {b.rho!r} {int(b.constant)}\n")
+                        fcase.write(f"{k}\n1 1 1\n0\n")
+                    env = dict(os.environ, OMP_NUM_THREADS=str(cores))
+                    txt = subprocess.run([exe, case, out], env=env, check=True, stdout=subprocess.PIPE,
+                                         universal_newlines=True, timeout=600).stdout
+                    return float(txt.split("REF_SWEEP_SECONDS")[1].split()[0])
+            t2 = run(2)
+            k = int(max(2, min(400, seconds_target / max(t2 / 2, 1e-6))))
+            t = run(k)
+            return dict(value=n[0] * n[1] * n[2] * k / t / 1e9, unit="GLUP/s", cores=cores, kind="reference",
+                        sample=f"{k} gs_step sweeps (reference's lexicographic OpenMP smoother, amdflang -O2 -fopenmp, "
+                               f"fp64 build) on {n[0]}x{n[1]}x{n[2]} of the bench geometry, {t:.1f} s")
+        except Exception as e:   # binary not runnable here: fall through to the port
+            sys.stderr.write(f"[bench] reference binary failed ({e}); timing the C oracle instead\n")
+    from oracle import oracle as orc
+    from tests.helpers import oracle_levels
+    L = oracle_levels(top)[0]
+    V = np.zeros(L.shape())
+    orc.setup(L, V, True)
+    t0 = time.perf_counter()
+    k = 0
+    while time.perf_counter() - t0 < seconds_target:
+        orc.sweep(L, V, orc.ORDER_RB)
+        k += 1
+    t = time.perf_counter() - t0
+    return dict(value=n[0] * n[1] * n[2] * k / t / 1e9, unit="GLUP/s", cores=1, kind="port",
+                sample=f"{k} red-black sweeps of the C oracle (1 thread) on {n[0]}x{n[1]}x{n[2]}, {t:.1f} s")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=50)
+    ap.add_argument("--warmup", type=int, default=5)
+    ap.add_argument("--n", type=int, default=512, help="cells per dimension of one GPU's slab")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-vcycle", action="store_true")
+    ap.add_argument("--vcycle-tol", default="1.e-8")
+    ap.add_argument("--sor", default="1.7")
+    ap.add_argument("--kernel", type=int, default=0, help="0 auto, 1 two-pass, 2 fused")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from multigrid_amd import cycle, lib, mgio
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    torch.cuda.set_device(local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    n = args.n
+    stream = torch.cuda.current_stream().cuda_stream
+    ctx = lib.Context(local_rank, stream)
+    ctx.set_kernel(args.kernel)
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+
+    if world == 1:
+        top = mgio.iomg_read(mgio.MgIO(text=config3_input((n, n, n), tol=args.vcycle_tol, sor=args.sor)))
+        solver = cycle.Solver(top, ctx=ctx)
+        solver.bring_back(top)
+        solver.setup(top, True)
+        lv = top.dev
+
+        def step():
+            lv.sweep(1, lib.RED_ERR | lib.RED_SUM)
+        fetch = lv.result
+        cells_per_step = n ** 3
+    else:
+        from multigrid_amd import slab
+        text = config3_input((n, n, n * world), tol=args.vcycle_tol, sor=args.sor)
+        top = mgio.iomg_read(mgio.MgIO(text=text))
+        sl = slab.SlabLevel(ctx, top, rank, world)
+        sl.setup(True)
+        step = sl.sweep
+        fetch = sl.result
+        cells_per_step = n ** 3 * world
+
+    for _ in range(args.warmup):
+        step()
+    fetch()
+    barrier()
+    t0 = time.perf_counter()
+    ev0.record()
+    for _ in range(args.steps):
+        step()
+    ev1.record()
+    barrier()
+    t1 = time.perf_counter()
+    e2, s, _ = fetch()
+    dt = torch.tensor([t1 - t0], dtype=torch.float64, device="cuda")
+    if world > 1:
+        dist.all_reduce(dt, op=dist.ReduceOp.MAX)
+    wall = float(dt.item())
+    ms_per_step = wall / args.steps * 1e3
+    kernel_ms = ev0.elapsed_time(ev1) / args.steps          # device time of one sweep on the kernel's stream
+    glups = cells_per_step / (wall / args.steps) / 1e9
+    achieved = BYTES_PER_LUP * (n ** 3) / (kernel_ms * 1e-3) / 1e9   # per GPU
+
+    out = {
+        "metric": METRIC, "value": glups, "unit": "GLUP/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
+        "data": "synthetic",
+        "config": {"workload": f"config 3: {n}x{n}x{n * world} mixed periodic/Neumann/Dirichlet, 2 plate electrodes + rho=3 block, "
+                               f"finest level, one red-black SOR sweep with fused err/sum reductions per step",
+                   "parallelism": "single GPU" if world == 1 else f"z-slab x{world}", "sor": float(args.sor)},
+        "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                     "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                     "kernel_ms": kernel_ms, "bytes_per_lup": BYTES_PER_LUP},
+        "hbm_peak_pct": 100.0 * achieved / HBM_PEAK_GBS,
+        "check": {"err_sq_max": e2, "abs_sum": s},
+    }
+    tr = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(tr):
+        try:
+            out["roofline"]["traffic"] = json.load(open(tr)).get("hbm_bytes_per_launch")
+        except Exception:
+            pass
+
+    if world == 1 and not args.no_vcycle:
+        # complete `method v-cycle` solve of the same input (fresh state), timed to its own tolerance
+        for g in top.levels():
+            g.itt = 0
+        solver.history = []
+        solver.total_sweeps = 0
+        solver.print_sums = True
+        torch.cuda.synchronize()
+        tv0 = time.perf_counter()
+        status = "converged"
+        try:
+            solver.max_sweeps = 200000
+            solver.mg_gs_cds(cycle.CDS_W_CYCLE)
+        except Exception as e:
+            status = f"stopped: {e}"
+        torch.cuda.synchronize()
+        tv = time.perf_counter() - tv0
+        h = solver.history_array()
+        out["vcycle"] = {"seconds": tv, "status": status, "tol": float(args.vcycle_tol),
+                         "sweeps_per_level": [int(g.itt) for g in top.levels()],
+                         "levels": [[int(v) for v in g.n] for g in top.levels()],
+                         "final_err": float(h["err"][-1]) if len(h) else None,
+                         "lattice_updates": int(sum(int(g.itt) * int(np.prod(g.n)) for g in top.levels()))}
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline()
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
