@@ -157,8 +157,11 @@ def main():
         torch.cuda.synchronize()
 
     n = args.n
-    stream = torch.cuda.current_stream().cuda_stream
-    ctx = lib.Context(local_rank, stream)
+    # a stream of torch's own (the default stream has handle 0): the library enqueues on it, so the
+    # events below bracket exactly the kernels of the timed region
+    tstream = torch.cuda.Stream()
+    torch.cuda.set_stream(tstream)
+    ctx = lib.Context(local_rank, tstream.cuda_stream)
     ctx.set_kernel(args.kernel)
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 

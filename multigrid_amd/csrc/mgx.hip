@@ -74,6 +74,7 @@ struct mgx_level {
   int nbox = 0;
   long long count_cache = -1;
   u64 *d_res = nullptr;        // MGX_RES_WORDS words
+  MgxFusedPlan plan;           // tile lists of the fused sweep (rebuilt when the boxes change)
 };
 
 static inline mgx_ctx *C(mgx_level *lv) { return lv->ctx; }
@@ -116,6 +117,7 @@ extern "C" int mgx_ctx_create(int device, void *stream, mgx_ctx **out) {
   mgx_ctx *c = new mgx_ctx();
   c->device = device;
   if (const char *e = getenv("MGX_FUSED_TY")) mgx_fused_ty = atoi(e);   // tile-height override for benchmarking
+  if (const char *e = getenv("MGX_FUSED_DEPTH")) mgx_fused_depth = atoi(e);
   if (stream) {
     c->stream = (hipStream_t)stream;
   } else {
@@ -211,6 +213,7 @@ extern "C" int mgx_level_destroy(mgx_level *lv) {
   (void)hipFree(lv->buf[1]);
   (void)hipFree(lv->d_res);
   if (lv->d_boxes) (void)hipFree(lv->d_boxes);
+  if (lv->plan.d_tiles) (void)hipFree(lv->plan.d_tiles);
   delete lv;
   return MGX_OK;
 }
@@ -265,6 +268,7 @@ extern "C" int mgx_level_set_boxes(mgx_level *lv, int32_t nbox, const int32_t *p
   }
   lv->nbox = nbox;
   lv->count_cache = -1;
+  lv->plan.valid = false;
   return MGX_OK;
 }
 
@@ -373,7 +377,9 @@ static int do_sweeps(mgx_level *lv, int nsweeps, int reduce) {
     if (red) TRY(reset_result(lv));
     if (which == MGX_KERNEL_FUSED) {
       TRY(sync_shell<T>(lv));
-      if (mgx_fused_launch<T>((const T *)lv->buf[lv->cur], (T *)lv->buf[1 - lv->cur], g, make_params<T>(lv),
+      if (!lv->plan.valid && mgx_fused_make_plan(lv->plan, g, lv->boxes, C(lv)->stream) != 0)
+        return fail(MGX_EHIP, "mgx_level_sweep: could not build the tile lists of the fused kernel");
+      if (mgx_fused_launch<T>(lv->plan, (const T *)lv->buf[lv->cur], (T *)lv->buf[1 - lv->cur], g, make_params<T>(lv),
                               lv->d_boxes, lv->nbox, red, lv->d_res, C(lv)->stream) != 0)
         return fail(MGX_EHIP, "mgx_level_sweep: fused kernel launch configuration failed");
       HIP_TRY(hipGetLastError());

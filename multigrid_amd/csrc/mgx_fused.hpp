@@ -93,7 +93,22 @@ __device__ inline T mgx_cell_new_sets(const T vc, const T vxm, const T vxp, cons
   return p.s1 * vc + p.s2 * avg;
 }
 
-template <typename T, int TY, bool BOXES>
+// branch-free form of mgx_exact_add (same integer result)
+__device__ inline void mgx_exact_add_nb(u64 &lo, u64 &hi, double a, unsigned &ovf) {
+  const u64 bits = (u64)__double_as_longlong(a) & 0x7FFFFFFFFFFFFFFFull;
+  const int e = (int)(bits >> 52);
+  u64 m = bits & 0x000FFFFFFFFFFFFFull;
+  ovf |= (e >= 1023 + 20) ? 1u : 0u;
+  m |= e ? (1ull << 52) : 0ull;
+  const int sh = (e ? e : 1) - 1075 + MGX_SUM_Q;
+  const int shl = min(max(sh, 0), 63), shr = min(max(-sh, 0), 63);
+  const u64 alo = sh >= 0 ? (m << shl) : (m >> shr);
+  const u64 ahi = sh >= 0 ? ((m >> 1) >> (63 - shl)) : 0ull;
+  lo += alo;
+  hi += ahi + (lo < alo ? 1ull : 0ull);
+}
+
+template <typename T, int TY, bool BOXES, int D>
 __device__ inline void mgx_fused_body(const T *__restrict__ src, T *__restrict__ dst, const MgxGeom &g,
                                       const MgxSweepParams<T> &p, const MgxBox *__restrict__ bx, const int nb,
                                       const int tx0, const int ty0, const int zc0, const int zc1, const int reduce,
@@ -102,16 +117,19 @@ __device__ inline void mgx_fused_body(const T *__restrict__ src, T *__restrict__
   constexpr int TXP = 64;
   constexpr int LP = TXP + 2;            // pairs per staged row
   constexpr int LR = TY + 4;             // staged rows
-  constexpr int PL = LP * LR;            // pairs per staged plane
+  constexpr int PL = LP * (LR + 2);      // pairs per staged plane incl. one guard row above and below
   constexpr int R = LR / 4;              // rows per row-wave
+  constexpr int NSET = 3 + D;            // register plane sets
   static_assert(LR % 4 == 0, "staged rows must divide over four waves");
   static_assert(2 * LR <= 64, "halo pairs must fit one wave");
   auto L = [&](int slot, int comp, int li) -> T & { return lds[(slot * 2 + comp) * PL + li]; };
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 
-  // ---- items of this lane ----
-  int li[R], fl[R], iy[R], ixs[R];
-  long long go[R];
+  // ---- items of this lane.  Everything below is branch-free per item: items (or cells) that must not be
+  // touched compute anyway and are masked by value selects; their loads, LDS writes and stores are
+  // redirected to harmless addresses (element 0 of the buffers' leading pad, LDS guard row). ----
+  int li[R], fl[R], iy[R];
+  long long go[R], gst[R];
   unsigned mx[R][4], my[R][3];           // BOXES: boxes whose x range holds xs-1..xs+2 / y range holds y-1..y+1
 #pragma unroll
   for (int j = 0; j < R; ++j) {
@@ -135,13 +153,12 @@ __device__ inline void mgx_fused_body(const T *__restrict__ src, T *__restrict__
         if (x0ok) f |= MGX_F_STORE;
       }
     }
-    li[j] = r * LP + pc;
+    const bool ld = (f & MGX_F_LOAD) != 0;
+    li[j] = ld ? (r + 1) * LP + pc : 0;
     fl[j] = f;
     iy[j] = y;
-    ixs[j] = xs;
-    // pairs that do not exist are fetched from a harmless address instead of being predicated, so that no
-    // branch (and no wait) sits between a load and its first use
-    go[j] = (f & MGX_F_LOAD) ? g.front + (long long)(xs - 1) + (long long)g.px * y : g.front;
+    go[j] = ld ? g.front + (long long)(xs - 1) + (long long)g.px * y : g.front;
+    gst[j] = (f & MGX_F_STORE) ? go[j] : -1;
     if (BOXES) {
 #pragma unroll
       for (int d = 0; d < 4; ++d) mx[j][d] = 0u;
@@ -178,29 +195,44 @@ __device__ inline void mgx_fused_body(const T *__restrict__ src, T *__restrict__
   };
   const long long pzl = g.pz;
 
-  // register window of every pair: planes k-1 (m*), k (c*), k+1 (n*), k+2 in flight (i*); component 0 / 1
-  // kept as separate scalars so that the colour select is a value select, never an address select
-  T m0[R], m1[R], c0[R], c1[R], n0[R], n1[R], i0[R], i1[R], below[R];
-#define MGX_FETCH(z, a0, a1)                                                           \
+  // Row waves know per item (wave-uniformly) whether the row takes part in the black / red phase at all
+  int rowf[R];
+#pragma unroll
+  for (int j = 0; j < R; ++j) {
+    const int r = wave + 4 * j;
+    int f = MGX_F_BLK0 | MGX_F_RED0;                       // wave 4: decide per lane
+    if (wave < 4) f = ((r >= 1 && r <= LR - 2) ? MGX_F_BLK0 : 0) | ((r >= 2 && r <= LR - 3) ? MGX_F_RED0 : 0);
+    rowf[j] = __builtin_amdgcn_readfirstlane(f);
+  }
+
+  // Register window of every pair: NSET plane sets used round-robin (the k loop is unrolled NSET times so
+  // that a set changes role by renaming, never by a copy: a copy would make the wave wait for the newest
+  // load).  At step k (position u in the unrolled group) W[u] = plane k-1, W[u+1] = plane k,
+  // W[u+2] = plane k+1, ..., W[u+NSET-1] = plane k+1+D, fetched now and first needed D steps later.
+  // A set holds a pair by COLOUR, not by position: WB = the odd ("black") cell, WR = the even ("red")
+  // cell.  Which of the two sits first in memory alternates with y + z; that only matters when a pair
+  // is fetched or stored and for the side of the x neighbour in the adjacent pair, so the arithmetic
+  // below is free of position selects.  LDS likewise: array 0 of a slot = black values, array 1 = red.
+  T WB[NSET][R], WR[NSET][R], below[R];
+#define MGX_FETCH(z, aB, aR)                                                           \
   {                                                                                    \
     const long long pb_ = pzl * ((z) + 1);                                             \
     _Pragma("unroll") for (int j = 0; j < R; ++j) {                                    \
       const V2 t_ = *reinterpret_cast<const V2 *>(src + pb_ + go[j]);                  \
-      a0[j] = t_.x; a1[j] = t_.y;                                                      \
+      const bool q_ = ((iy[j] + (z) + g.z0) & 1) != 0;   /* odd cell is the second one */ \
+      aB[j] = q_ ? t_.y : t_.x; aR[j] = q_ ? t_.x : t_.y;                              \
     }                                                                                  \
   }
-#define MGX_STAGE(slot, a0, a1)                                                        \
+#define MGX_STAGE(slot, aB, aR)                                                        \
   {                                                                                    \
-    _Pragma("unroll") for (int j = 0; j < R; ++j)                                      \
-      if (fl[j] & MGX_F_LOAD) { L(slot, 0, li[j]) = a0[j]; L(slot, 1, li[j]) = a1[j]; } \
+    _Pragma("unroll") for (int j = 0; j < R; ++j) { L(slot, 0, li[j]) = aB[j]; L(slot, 1, li[j]) = aR[j]; } \
   }
 #pragma unroll
-  for (int j = 0; j < R; ++j) { i0[j] = i1[j] = below[j] = (T)0; }
-  MGX_FETCH(zc0 - 2, m0, m1)
-  MGX_FETCH(zc0 - 1, c0, c1)
-  MGX_FETCH(zc0, n0, n1)
+  for (int j = 0; j < R; ++j) { WB[NSET - 1][j] = WR[NSET - 1][j] = below[j] = (T)0; }
+#pragma unroll
+  for (int sI = 0; sI < NSET - 1; ++sI) MGX_FETCH(zc0 - 2 + sI, WB[sI], WR[sI])
   int sk = 0;                      // LDS slot of plane k; k-1 lives in sk-1, k+1 in sk+1 (mod 3)
-  MGX_STAGE(sk, c0, c1)
+  MGX_STAGE(sk, WB[1], WR[1])
   make_zsets(zc0 - 1 + g.z0, (zc0 - 1) & 1);
   __syncthreads();
 
@@ -209,64 +241,74 @@ __device__ inline void mgx_fused_body(const T *__restrict__ src, T *__restrict__
   unsigned ovf = 0;
   unsigned zmm = 0u;               // Z set of plane k-2
 
-  for (int k = zc0 - 1; k <= zc1 + 1; ++k) {
-    const int zg = k + g.z0;
-    const int sm = sk == 0 ? 2 : sk - 1, sp = sk == 2 ? 0 : sk + 1;
-    if (k + 2 <= zc1 + 2) MGX_FETCH(k + 2, i0, i1)
-    unsigned zm = 0u, z0s = 0u, zp = 0u;
-    if (BOXES) { zm = bl->zsets[k & 1][0]; z0s = bl->zsets[k & 1][1]; zp = bl->zsets[k & 1][2]; }
-
-    // ---------------- black cells of plane k ----------------
-    if (zg >= 1 && zg <= g.n3g) {
-      const bool zown = k >= zc0 && k <= zc1;
+  for (int kb = zc0 - 1; kb <= zc1 + 1; kb += NSET) {
 #pragma unroll
-      for (int j = 0; j < R; ++j) {
-        const int q = (iy[j] + zg) & 1;                     // component holding the odd cell (pairs start at odd x)
-        if (fl[j] & (q ? MGX_F_BLK1 : MGX_F_BLK0)) {
-          const T vc = q ? c1[j] : c0[j];
-          const T partner = q ? c0[j] : c1[j];
-          const T other = L(sk, 1 - q, li[j] + (2 * q - 1));
-          const T vym = L(sk, q, li[j] - LP), vyp = L(sk, q, li[j] + LP);
-          const T vzm = q ? m1[j] : m0[j], vzp = q ? n1[j] : n0[j];
-          T vv;
-          if (BOXES) {
-            const unsigned X0 = q ? mx[j][2] : mx[j][1], Xm = q ? mx[j][1] : mx[j][0], Xp = q ? mx[j][3] : mx[j][2];
-            const unsigned XY = X0 & my[j][1];
-            vv = mgx_cell_new_sets<T>(vc, q ? partner : other, q ? other : partner, vym, vyp, vzm, vzp, XY & z0s,
-                                      Xm & my[j][1] & z0s, Xp & my[j][1] & z0s, X0 & my[j][0] & z0s,
-                                      X0 & my[j][2] & z0s, XY & zm, XY & zp, cmask, rmask, bl->rho, p);
-          } else {
-            vv = p.s1 * vc + p.s2 * mgx_avg_uniform<T>(q ? partner : other, q ? other : partner, vym, vyp, vzm, vzp, p.w);
-          }
-          c0[j] = q ? c0[j] : vv;
-          c1[j] = q ? vv : c1[j];
-          L(sk, q, li[j]) = vv;
-          if (zown && (fl[j] & (q ? MGX_F_OWN1 : MGX_F_OWN0))) {
-            const T d = vv - vc;
-            const T d2 = d * d;
-            err = d2 > err ? d2 : err;
-            if (reduce & 2) mgx_exact_add(slo, shi, (double)(vv < (T)0 ? -vv : vv), ovf);
+    for (int u = 0; u < NSET; ++u) {
+      const int k = kb + u;
+      if (k > zc1 + 1) break;
+      T(&mB)[R] = WB[u % NSET], (&mR)[R] = WR[u % NSET];
+      T(&cB)[R] = WB[(u + 1) % NSET], (&cR)[R] = WR[(u + 1) % NSET];
+      T(&nR)[R] = WR[(u + 2) % NSET];
+      T(&nB)[R] = WB[(u + 2) % NSET];
+      T(&fB)[R] = WB[(u + NSET - 1) % NSET], (&fR)[R] = WR[(u + NSET - 1) % NSET];
+      const int zg = k + g.z0;
+      const int sm = sk == 0 ? 2 : sk - 1, sp = sk == 2 ? 0 : sk + 1;
+      if (k + 1 + D <= zc1 + 2) MGX_FETCH(k + 1 + D, fB, fR)
+      unsigned zm = 0u, z0s = 0u, zp = 0u;
+      if (BOXES) { zm = bl->zsets[k & 1][0]; z0s = bl->zsets[k & 1][1]; zp = bl->zsets[k & 1][2]; }
+
+      // ---------------- black cells of plane k ----------------
+      if (zg >= 1 && zg <= g.n3g) {
+        const bool zown = k >= zc0 && k <= zc1;
+#pragma unroll
+        for (int j = 0; j < R; ++j) {
+          if (rowf[j] & MGX_F_BLK0) {
+            const int q = (iy[j] + zg) & 1;                 // position of the odd cell in the pair
+            const bool act = (fl[j] & (q ? MGX_F_BLK1 : MGX_F_BLK0)) != 0;
+            const T vc = cB[j], partner = cR[j];
+            const T other = L(sk, 1, li[j] + (2 * q - 1));
+            const T vym = L(sk, 1, li[j] - LP), vyp = L(sk, 1, li[j] + LP);
+            const T vzm = mR[j], vzp = nR[j];
+            T vv;
+            if (BOXES) {
+              const unsigned X0 = q ? mx[j][2] : mx[j][1], Xm = q ? mx[j][1] : mx[j][0], Xp = q ? mx[j][3] : mx[j][2];
+              const unsigned XY = X0 & my[j][1];
+              vv = mgx_cell_new_sets<T>(vc, q ? partner : other, q ? other : partner, vym, vyp, vzm, vzp, XY & z0s,
+                                        Xm & my[j][1] & z0s, Xp & my[j][1] & z0s, X0 & my[j][0] & z0s,
+                                        X0 & my[j][2] & z0s, XY & zm, XY & zp, cmask, rmask, bl->rho, p);
+            } else {
+              // x-1 and x+1 carry the same weight and a*w + b*w commutes exactly: no need to order them
+              vv = p.s1 * vc + p.s2 * mgx_avg_uniform<T>(partner, other, vym, vyp, vzm, vzp, p.w);
+            }
+            vv = act ? vv : vc;
+            cB[j] = vv;
+            L(sk, 0, li[j]) = vv;
+            if (reduce) {
+              const bool own = act && zown && (fl[j] & (q ? MGX_F_OWN1 : MGX_F_OWN0)) != 0;
+              const T d = vv - vc;
+              const T d2 = own ? d * d : (T)0;
+              err = d2 > err ? d2 : err;
+              if (reduce & 2) mgx_exact_add_nb(slo, shi, own ? (double)(vv < (T)0 ? -vv : vv) : 0.0, ovf);
+            }
           }
         }
       }
-    }
-    make_zsets(zg + 1, (k + 1) & 1);                        // for the next step; this step reads the other parity
-    __syncthreads();
+      make_zsets(zg + 1, (k + 1) & 1);                      // for the next step; this step reads the other parity
+      __syncthreads();
 
-    // ---------------- red cells of plane k-1; store the finished plane ----------------
-    if (k - 1 >= zc0) {
-      const int kr = k - 1, zgr = kr + g.z0;
-      const long long pb = pzl * (kr + 1);
+      // ---------------- red cells of plane k-1; store the finished plane ----------------
+      if (k - 1 >= zc0 && wave < 4) {
+        const int kr = k - 1, zgr = kr + g.z0;
+        const long long pb = pzl * (kr + 1);
 #pragma unroll
-      for (int j = 0; j < R; ++j) {
-        const int q = (1 + iy[j] + zgr) & 1;                // component holding the even cell
-        if (fl[j] & MGX_F_STORE) {
-          if (fl[j] & (q ? MGX_F_RED1 : MGX_F_RED0)) {
-            const T vc = q ? m1[j] : m0[j];
-            const T partner = q ? m0[j] : m1[j];
-            const T other = L(sm, 1 - q, li[j] + (2 * q - 1));
-            const T vym = L(sm, q, li[j] - LP), vyp = L(sm, q, li[j] + LP);
-            const T vzp = q ? c1[j] : c0[j];
+        for (int j = 0; j < R; ++j) {
+          if (rowf[j] & MGX_F_RED0) {
+            const int q = (1 + iy[j] + zgr) & 1;            // position of the even cell in the pair
+            const bool act = (fl[j] & (q ? MGX_F_RED1 : MGX_F_RED0)) != 0;
+            const T vc = mR[j], partner = mB[j];
+            const T other = L(sm, 0, li[j] + (2 * q - 1));
+            const T vym = L(sm, 0, li[j] - LP), vyp = L(sm, 0, li[j] + LP);
+            const T vzp = cB[j];
             T vv;
             if (BOXES) {
               const unsigned X0 = q ? mx[j][2] : mx[j][1], Xm = q ? mx[j][1] : mx[j][0], Xp = q ? mx[j][3] : mx[j][2];
@@ -275,35 +317,31 @@ __device__ inline void mgx_fused_body(const T *__restrict__ src, T *__restrict__
                                         Xm & my[j][1] & zm, Xp & my[j][1] & zm, X0 & my[j][0] & zm,
                                         X0 & my[j][2] & zm, XY & zmm, XY & z0s, cmask, rmask, bl->rho, p);
             } else {
-              vv = p.s1 * vc + p.s2 * mgx_avg_uniform<T>(q ? partner : other, q ? other : partner, vym, vyp, below[j], vzp, p.w);
+              vv = p.s1 * vc + p.s2 * mgx_avg_uniform<T>(partner, other, vym, vyp, below[j], vzp, p.w);
             }
-            m0[j] = q ? m0[j] : vv;
-            m1[j] = q ? vv : m1[j];
-            const T d = vv - vc;
-            const T d2 = d * d;
-            err = d2 > err ? d2 : err;
-            if (reduce & 2) mgx_exact_add(slo, shi, (double)(vv < (T)0 ? -vv : vv), ovf);
+            vv = act ? vv : vc;
+            if (reduce) {
+              const T d = vv - vc;
+              const T d2 = act ? d * d : (T)0;
+              err = d2 > err ? d2 : err;
+              if (reduce & 2) mgx_exact_add_nb(slo, shi, act ? (double)(vv < (T)0 ? -vv : vv) : 0.0, ovf);
+            }
+            V2 out;
+            out.x = q ? partner : vv;
+            out.y = q ? vv : partner;
+            *reinterpret_cast<V2 *>(dst + (gst[j] >= 0 ? pb + gst[j] : 0)) = out;
           }
-          V2 out;
-          out.x = m0[j]; out.y = m1[j];
-          *reinterpret_cast<V2 *>(dst + pb + go[j]) = out;
         }
       }
-    }
 
-    // ---------------- stage raw plane k+1, rotate the window ----------------
-    MGX_STAGE(sp, n0, n1)
+      // ---------------- stage raw plane k+1; remember the black value under the next red plane ----------------
+      MGX_STAGE(sp, nB, nR)
 #pragma unroll
-    for (int j = 0; j < R; ++j) {
-      const int q = (iy[j] + k - 1 + g.z0) & 1;             // component of the odd (black) cell on plane k-1
-      below[j] = q ? m1[j] : m0[j];
-      m0[j] = c0[j]; m1[j] = c1[j];
-      c0[j] = n0[j]; c1[j] = n1[j];
-      n0[j] = i0[j]; n1[j] = i1[j];
+      for (int j = 0; j < R; ++j) below[j] = mB[j];
+      sk = sp;
+      zmm = zm;                                             // Z set of plane k-1 = (k+1)-2 for the next red phase
+      __syncthreads();
     }
-    sk = sp;
-    zmm = zm;                                               // Z set of plane k-1 = (k+1)-2 for the next red phase
-    __syncthreads();
   }
 #undef MGX_FETCH
 #undef MGX_STAGE
@@ -311,54 +349,104 @@ __device__ inline void mgx_fused_body(const T *__restrict__ src, T *__restrict__
   if (reduce) mgx_block_commit<5>((double)err, slo, shi, ovf, reduce, res);
 }
 
-template <typename T, int TY>
+// One launch per tile class: `tiles` lists the tiles (x fastest, then y, then z chunk) that boxes do not
+// reach (BOXES = false) or do reach (BOXES = true); the host builds both lists from the box table.
+template <typename T, int TY, bool BOXES, int D>
 __global__ __launch_bounds__(320) void k_fused_sweep(const T *__restrict__ src, T *__restrict__ dst, const MgxGeom g,
                                                      const MgxSweepParams<T> p, const MgxBox *__restrict__ bx,
                                                      const int nb, const int ZC, const int ntx, const int nty,
-                                                     const int reduce, u64 *__restrict__ res) {
+                                                     const int *__restrict__ tiles, const int reduce,
+                                                     u64 *__restrict__ res) {
   constexpr int TXP = 64;
   extern __shared__ __align__(16) unsigned char mgx_lds_raw[];
   T *lds = reinterpret_cast<T *>(mgx_lds_raw);          // [slot 0..2][comp 0..1][pairs of a staged plane]
-  MgxBoxLds<T> *bl = reinterpret_cast<MgxBoxLds<T> *>(lds + 3 * 2 * (TXP + 2) * (TY + 4));
+  MgxBoxLds<T> *bl = reinterpret_cast<MgxBoxLds<T> *>(lds + 3 * 2 * (TXP + 2) * (TY + 6));
 
-  // tile of this block; blocks that share an XCD (same blockIdx % 8) get consecutive tiles
+  // blocks that share an XCD (same blockIdx % 8) get consecutive list entries, i.e. neighbouring tiles
   int lid;
   {
     const int nblk = gridDim.x, b = blockIdx.x, xcd = b & 7, q = nblk >> 3, r = nblk & 7;
     lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
   }
+  lid = tiles[lid];
   const int tx = lid % ntx, ty = (lid / ntx) % nty, tz = lid / (ntx * nty);
   const int tx0 = 1 + tx * 2 * TXP, ty0 = 1 + ty * TY;
   const int zc0 = 1 + tz * ZC, zc1 = min(zc0 + ZC - 1, g.n3);
-
-  // does any box reach a position this tile ever asks about (cells grown by one, plus their neighbours)?
-  const int cls = mgx_classify(bx, nb, tx0 - 1, tx0 + 2 * TXP, ty0 - 1, ty0 + TY, zc0 - 1 + g.z0, zc1 + 1 + g.z0);
-  if (cls == 0) mgx_fused_body<T, TY, false>(src, dst, g, p, bx, nb, tx0, ty0, zc0, zc1, reduce, res, lds, bl);
-  else mgx_fused_body<T, TY, true>(src, dst, g, p, bx, nb, tx0, ty0, zc0, zc1, reduce, res, lds, bl);
+  mgx_fused_body<T, TY, BOXES, D>(src, dst, g, p, bx, nb, tx0, ty0, zc0, zc1, reduce, res, lds, bl);
 }
 
 // ------------------------------------------------------------------------------------------------
 // host side
 
-template <typename T, int TY>
-static int mgx_fused_launch_cfg(const T *src, T *dst, const MgxGeom &g, const MgxSweepParams<T> &p, const MgxBox *bx,
-                                int nb, int reduce, u64 *res, hipStream_t st) {
+struct MgxFusedPlan {            // per level: tile decomposition and the two tile lists (device)
+  int ty = 0, ZC = 0, ntx = 0, nty = 0, nzc = 0;
+  int n_fast = 0, n_box = 0;
+  int *d_tiles = nullptr;        // n_fast entries, then n_box entries
+  bool valid = false;
+};
+
+static int mgx_fused_ty = 8;     // tile height selector (8, 12 or 16), settable for benchmarking
+static int mgx_fused_depth = 1;  // planes fetched ahead of their first use (1 or 2)
+
+// (re)build the plan: which tiles can any box reach?  A tile asks about cells of its footprint grown by
+// one and about their neighbours, i.e. positions grown by two, on planes zc0-2 .. zc1+2.
+static int mgx_fused_make_plan(MgxFusedPlan &pl, const MgxGeom &g, const std::vector<MgxBox> &boxes, hipStream_t st) {
   constexpr int TXP = 64;
-  constexpr size_t lds = (size_t)3 * 2 * (TXP + 2) * (TY + 4) * sizeof(T) + sizeof(MgxBoxLds<T>);
-  auto kern = k_fused_sweep<T, TY>;
-  if (lds > 64 * 1024 &&
-      hipFuncSetAttribute(reinterpret_cast<const void *>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
-    return -1;
-  const int ntx = (g.n1 + 2 * TXP - 1) / (2 * TXP), nty = (g.n2 + TY - 1) / TY;
+  if (pl.d_tiles) { (void)hipFree(pl.d_tiles); pl.d_tiles = nullptr; }
+  pl.valid = false;
+  pl.ty = (mgx_fused_ty == 16 || mgx_fused_ty == 12) ? mgx_fused_ty : 8;
+  pl.ntx = (g.n1 + 2 * TXP - 1) / (2 * TXP);
+  pl.nty = (g.n2 + pl.ty - 1) / pl.ty;
   // z chunk: enough blocks to fill 256 CUs several times over, but at least 16 planes per chunk so
-  // that the four extra planes a chunk fetches stay cheap
+  // that the extra planes a chunk fetches stay cheap
   int ZC = g.n3;
-  const long long per_chunk = (long long)ntx * nty;
+  const long long per_chunk = (long long)pl.ntx * pl.nty;
   while (ZC > 16 && per_chunk * ((g.n3 + ZC - 1) / ZC) < 4096) ZC = (ZC + 1) / 2;
-  const int nzc = (g.n3 + ZC - 1) / ZC;
-  const long long nblk = per_chunk * nzc;
-  if (nblk > 0x7fffffffLL) return -1;
-  hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(320), lds, st, src, dst, g, p, bx, nb, ZC, ntx, nty, reduce, res);
+  pl.ZC = ZC;
+  pl.nzc = (g.n3 + ZC - 1) / ZC;
+  const long long ntile = per_chunk * pl.nzc;
+  if (ntile > 0x7fffffffLL) return -1;
+  std::vector<int> fast, boxed;
+  for (int tz = 0; tz < pl.nzc; ++tz)
+    for (int ty = 0; ty < pl.nty; ++ty)
+      for (int tx = 0; tx < pl.ntx; ++tx) {
+        const int x0 = 1 + tx * 2 * TXP - 2, x1 = 1 + (tx + 1) * 2 * TXP + 1;
+        const int y0 = 1 + ty * pl.ty - 2, y1 = 1 + (ty + 1) * pl.ty + 1;
+        const int zc0 = 1 + tz * ZC, zc1 = std::min(zc0 + ZC - 1, g.n3);
+        const int z0 = zc0 - 2 + g.z0, z1 = zc1 + 2 + g.z0;
+        bool hit = false;
+        for (const MgxBox &b : boxes)
+          hit |= b.lo[0] <= x1 && x0 <= b.hi[0] && b.lo[1] <= y1 && y0 <= b.hi[1] && b.lo[2] <= z1 && z0 <= b.hi[2];
+        (hit ? boxed : fast).push_back((tz * pl.nty + ty) * pl.ntx + tx);
+      }
+  pl.n_fast = (int)fast.size();
+  pl.n_box = (int)boxed.size();
+  fast.insert(fast.end(), boxed.begin(), boxed.end());
+  if (hipMalloc((void **)&pl.d_tiles, sizeof(int) * fast.size()) != hipSuccess) return -1;
+  if (hipMemcpyAsync(pl.d_tiles, fast.data(), sizeof(int) * fast.size(), hipMemcpyHostToDevice, st) != hipSuccess) return -1;
+  if (hipStreamSynchronize(st) != hipSuccess) return -1;     // `fast` goes out of scope
+  pl.valid = true;
+  return 0;
+}
+
+template <typename T, int TY, int D>
+static int mgx_fused_launch_cfg(const MgxFusedPlan &pl, const T *src, T *dst, const MgxGeom &g, const MgxSweepParams<T> &p,
+                                const MgxBox *bx, int nb, int reduce, u64 *res, hipStream_t st) {
+  constexpr int TXP = 64;
+  constexpr size_t lds = (size_t)3 * 2 * (TXP + 2) * (TY + 6) * sizeof(T) + sizeof(MgxBoxLds<T>);
+  if (lds > 64 * 1024) {      // beyond the default dynamic LDS limit: raise it for both kernels
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_fused_sweep<T, TY, false, D>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void *>(k_fused_sweep<T, TY, true, D>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+      return -1;
+  }
+  if (pl.n_fast > 0)
+    hipLaunchKernelGGL((k_fused_sweep<T, TY, false, D>), dim3((unsigned)pl.n_fast), dim3(320), lds, st, src, dst, g, p, bx, nb,
+                       pl.ZC, pl.ntx, pl.nty, pl.d_tiles, reduce, res);
+  if (pl.n_box > 0)
+    hipLaunchKernelGGL((k_fused_sweep<T, TY, true, D>), dim3((unsigned)pl.n_box), dim3(320), lds, st, src, dst, g, p, bx, nb,
+                       pl.ZC, pl.ntx, pl.nty, pl.d_tiles + pl.n_fast, reduce, res);
   return 0;
 }
 
@@ -368,14 +456,19 @@ static bool mgx_fused_supported(const MgxGeom &g, int nbox) {
   return g.n1 >= 1 && g.n2 >= 1 && g.n3 >= 1 && nbox <= MGX_MAX_FUSED_BOXES;
 }
 
-static int mgx_fused_ty = 8;     // tile height selector (8, 12 or 16), settable for benchmarking
-
 template <typename T>
-static int mgx_fused_launch(const T *src, T *dst, const MgxGeom &g, const MgxSweepParams<T> &p, const MgxBox *bx,
-                            int nb, int reduce, u64 *res, hipStream_t st) {
-  switch (mgx_fused_ty) {
-    case 16: return mgx_fused_launch_cfg<T, 16>(src, dst, g, p, bx, nb, reduce, res, st);
-    case 12: return mgx_fused_launch_cfg<T, 12>(src, dst, g, p, bx, nb, reduce, res, st);
-    default: return mgx_fused_launch_cfg<T, 8>(src, dst, g, p, bx, nb, reduce, res, st);
+static int mgx_fused_launch(const MgxFusedPlan &pl, const T *src, T *dst, const MgxGeom &g, const MgxSweepParams<T> &p,
+                            const MgxBox *bx, int nb, int reduce, u64 *res, hipStream_t st) {
+  if (mgx_fused_depth == 2) {
+    switch (pl.ty) {
+      case 16: return mgx_fused_launch_cfg<T, 16, 2>(pl, src, dst, g, p, bx, nb, reduce, res, st);
+      case 12: return mgx_fused_launch_cfg<T, 12, 2>(pl, src, dst, g, p, bx, nb, reduce, res, st);
+      default: return mgx_fused_launch_cfg<T, 8, 2>(pl, src, dst, g, p, bx, nb, reduce, res, st);
+    }
+  }
+  switch (pl.ty) {
+    case 16: return mgx_fused_launch_cfg<T, 16, 1>(pl, src, dst, g, p, bx, nb, reduce, res, st);
+    case 12: return mgx_fused_launch_cfg<T, 12, 1>(pl, src, dst, g, p, bx, nb, reduce, res, st);
+    default: return mgx_fused_launch_cfg<T, 8, 1>(pl, src, dst, g, p, bx, nb, reduce, res, st);
   }
 }
