@@ -117,7 +117,8 @@ extern "C" int mgx_ctx_create(int device, void *stream, mgx_ctx **out) {
   mgx_ctx *c = new mgx_ctx();
   c->device = device;
   if (const char *e = getenv("MGX_FUSED_TY")) mgx_fused_ty = atoi(e);   // tile-height override for benchmarking
-  if (const char *e = getenv("MGX_FUSED_DEPTH")) mgx_fused_depth = atoi(e);
+  if (const char *e = getenv("MGX_FUSED_NW")) mgx_fused_nw = atoi(e);
+  if (const char *e = getenv("MGX_FUSED_ZC")) mgx_fused_zc = atoi(e);
   if (stream) {
     c->stream = (hipStream_t)stream;
   } else {

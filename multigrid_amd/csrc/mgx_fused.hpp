@@ -32,6 +32,12 @@
 
 #include "mgx_kernels.hpp"
 
+#ifdef MGX_ABLATE_BARRIER
+#define MGX_SYNC() __builtin_amdgcn_s_waitcnt(0xc07f)
+#else
+#define MGX_SYNC() __syncthreads()
+#endif
+
 template <typename T> struct MgxVec2;
 template <> struct MgxVec2<double> { typedef double2 type; };
 template <> struct MgxVec2<float> { typedef float2 type; };
@@ -108,7 +114,7 @@ __device__ inline void mgx_exact_add_nb(u64 &lo, u64 &hi, double a, unsigned &ov
   hi += ahi + (lo < alo ? 1ull : 0ull);
 }
 
-template <typename T, int TY, bool BOXES, int D>
+template <typename T, int TY, bool BOXES, int NW>
 __device__ inline void mgx_fused_body(const T *__restrict__ src, T *__restrict__ dst, const MgxGeom &g,
                                       const MgxSweepParams<T> &p, const MgxBox *__restrict__ bx, const int nb,
                                       const int tx0, const int ty0, const int zc0, const int zc1, const int reduce,
@@ -118,9 +124,10 @@ __device__ inline void mgx_fused_body(const T *__restrict__ src, T *__restrict__
   constexpr int LP = TXP + 2;            // pairs per staged row
   constexpr int LR = TY + 4;             // staged rows
   constexpr int PL = LP * (LR + 2);      // pairs per staged plane incl. one guard row above and below
-  constexpr int R = LR / 4;              // rows per row-wave
+  constexpr int R = LR / NW;             // rows per row-wave
+  constexpr int D = 1;                   // planes fetched ahead of their first use
   constexpr int NSET = 3 + D;            // register plane sets
-  static_assert(LR % 4 == 0, "staged rows must divide over four waves");
+  static_assert(LR % NW == 0, "staged rows must divide over the row waves");
   static_assert(2 * LR <= 64, "halo pairs must fit one wave");
   auto L = [&](int slot, int comp, int li) -> T & { return lds[(slot * 2 + comp) * PL + li]; };
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -135,7 +142,7 @@ __device__ inline void mgx_fused_body(const T *__restrict__ src, T *__restrict__
   for (int j = 0; j < R; ++j) {
     int r, pc;
     bool valid;
-    if (wave < 4) { r = wave + 4 * j; pc = lane + 1; valid = true; }
+    if (wave < NW) { r = wave + NW * j; pc = lane + 1; valid = true; }
     else { r = lane >> 1; pc = (lane & 1) ? LP - 1 : 0; valid = (j == 0) && lane < 2 * LR; }
     const int y = ty0 - 2 + r, xs = tx0 - 2 + 2 * pc;
     const bool halo = (pc == 0 || pc == LP - 1);
@@ -180,12 +187,12 @@ __device__ inline void mgx_fused_body(const T *__restrict__ src, T *__restrict__
       cmask |= bx[b].constant ? (1u << b) : 0u;
       rmask |= bx[b].rho_is_one ? 0u : (1u << b);
     }
-    if (wave == 4 && lane < nb) { blo2 = bx[lane].lo[2]; bhi2 = bx[lane].hi[2]; }
+    if (wave == NW && lane < nb) { blo2 = bx[lane].lo[2]; bhi2 = bx[lane].hi[2]; }
     if (threadIdx.x <= MGX_MAX_FUSED_BOXES) bl->rho[threadIdx.x] = threadIdx.x < nb ? (T)bx[threadIdx.x].rho : (T)1;
   }
   // Z sets for planes zz-1, zz, zz+1 (global), written by wave 4 into parity slot `par`
   auto make_zsets = [&](int zz, int par) {
-    if (BOXES && wave == 4) {
+    if (BOXES && wave == NW) {
 #pragma unroll
       for (int d = 0; d < 3; ++d) {
         const unsigned long long m = __ballot(blo2 <= zz - 1 + d && zz - 1 + d <= bhi2);
@@ -194,16 +201,6 @@ __device__ inline void mgx_fused_body(const T *__restrict__ src, T *__restrict__
     }
   };
   const long long pzl = g.pz;
-
-  // Row waves know per item (wave-uniformly) whether the row takes part in the black / red phase at all
-  int rowf[R];
-#pragma unroll
-  for (int j = 0; j < R; ++j) {
-    const int r = wave + 4 * j;
-    int f = MGX_F_BLK0 | MGX_F_RED0;                       // wave 4: decide per lane
-    if (wave < 4) f = ((r >= 1 && r <= LR - 2) ? MGX_F_BLK0 : 0) | ((r >= 2 && r <= LR - 3) ? MGX_F_RED0 : 0);
-    rowf[j] = __builtin_amdgcn_readfirstlane(f);
-  }
 
   // Register window of every pair: NSET plane sets used round-robin (the k loop is unrolled NSET times so
   // that a set changes role by renaming, never by a copy: a copy would make the wave wait for the newest
@@ -214,13 +211,20 @@ __device__ inline void mgx_fused_body(const T *__restrict__ src, T *__restrict__
   // is fetched or stored and for the side of the x neighbour in the adjacent pair, so the arithmetic
   // below is free of position selects.  LDS likewise: array 0 of a slot = black values, array 1 = red.
   T WB[NSET][R], WR[NSET][R], below[R];
-#define MGX_FETCH(z, aB, aR)                                                           \
+#define MGX_FETCH(z, a0, a1) /* raw: first / second cell of the pair; nothing may touch them yet */ \
   {                                                                                    \
     const long long pb_ = pzl * ((z) + 1);                                             \
     _Pragma("unroll") for (int j = 0; j < R; ++j) {                                    \
       const V2 t_ = *reinterpret_cast<const V2 *>(src + pb_ + go[j]);                  \
+      a0[j] = t_.x; a1[j] = t_.y;                                                      \
+    }                                                                                  \
+  }
+#define MGX_COLOUR(z, aB, aR) /* in place: (first, second) -> (odd cell, even cell) of plane z */ \
+  {                                                                                    \
+    _Pragma("unroll") for (int j = 0; j < R; ++j) {                                    \
       const bool q_ = ((iy[j] + (z) + g.z0) & 1) != 0;   /* odd cell is the second one */ \
-      aB[j] = q_ ? t_.y : t_.x; aR[j] = q_ ? t_.x : t_.y;                              \
+      const T b_ = q_ ? aR[j] : aB[j], r_ = q_ ? aB[j] : aR[j];                        \
+      aB[j] = b_; aR[j] = r_;                                                          \
     }                                                                                  \
   }
 #define MGX_STAGE(slot, aB, aR)                                                        \
@@ -231,10 +235,12 @@ __device__ inline void mgx_fused_body(const T *__restrict__ src, T *__restrict__
   for (int j = 0; j < R; ++j) { WB[NSET - 1][j] = WR[NSET - 1][j] = below[j] = (T)0; }
 #pragma unroll
   for (int sI = 0; sI < NSET - 1; ++sI) MGX_FETCH(zc0 - 2 + sI, WB[sI], WR[sI])
+#pragma unroll
+  for (int sI = 0; sI < 2; ++sI) MGX_COLOUR(zc0 - 2 + sI, WB[sI], WR[sI])      // planes k-1 and k of the first step
   int sk = 0;                      // LDS slot of plane k; k-1 lives in sk-1, k+1 in sk+1 (mod 3)
   MGX_STAGE(sk, WB[1], WR[1])
   make_zsets(zc0 - 1 + g.z0, (zc0 - 1) & 1);
-  __syncthreads();
+  MGX_SYNC();
 
   T err = (T)0;
   u64 slo = 0, shi = 0;
@@ -254,82 +260,110 @@ __device__ inline void mgx_fused_body(const T *__restrict__ src, T *__restrict__
       const int zg = k + g.z0;
       const int sm = sk == 0 ? 2 : sk - 1, sp = sk == 2 ? 0 : sk + 1;
       if (k + 1 + D <= zc1 + 2) MGX_FETCH(k + 1 + D, fB, fR)
+      MGX_COLOUR(k + 1, nB, nR)                             // plane k+1 was fetched D steps ago: first touch now
       unsigned zm = 0u, z0s = 0u, zp = 0u;
       if (BOXES) { zm = bl->zsets[k & 1][0]; z0s = bl->zsets[k & 1][1]; zp = bl->zsets[k & 1][2]; }
 
       // ---------------- black cells of plane k ----------------
+      // (each phase: all LDS reads first, then all arithmetic, then the writes and the reductions, so that
+      // the items of a lane overlap; cells that must not change are masked by value selects)
       if (zg >= 1 && zg <= g.n3g) {
         const bool zown = k >= zc0 && k <= zc1;
+        T other[R], vym[R], vyp[R], vold[R];
+        bool actv[R];
 #pragma unroll
         for (int j = 0; j < R; ++j) {
-          if (rowf[j] & MGX_F_BLK0) {
-            const int q = (iy[j] + zg) & 1;                 // position of the odd cell in the pair
-            const bool act = (fl[j] & (q ? MGX_F_BLK1 : MGX_F_BLK0)) != 0;
-            const T vc = cB[j], partner = cR[j];
-            const T other = L(sk, 1, li[j] + (2 * q - 1));
-            const T vym = L(sk, 1, li[j] - LP), vyp = L(sk, 1, li[j] + LP);
-            const T vzm = mR[j], vzp = nR[j];
-            T vv;
-            if (BOXES) {
-              const unsigned X0 = q ? mx[j][2] : mx[j][1], Xm = q ? mx[j][1] : mx[j][0], Xp = q ? mx[j][3] : mx[j][2];
-              const unsigned XY = X0 & my[j][1];
-              vv = mgx_cell_new_sets<T>(vc, q ? partner : other, q ? other : partner, vym, vyp, vzm, vzp, XY & z0s,
-                                        Xm & my[j][1] & z0s, Xp & my[j][1] & z0s, X0 & my[j][0] & z0s,
-                                        X0 & my[j][2] & z0s, XY & zm, XY & zp, cmask, rmask, bl->rho, p);
-            } else {
-              // x-1 and x+1 carry the same weight and a*w + b*w commutes exactly: no need to order them
-              vv = p.s1 * vc + p.s2 * mgx_avg_uniform<T>(partner, other, vym, vyp, vzm, vzp, p.w);
-            }
-            vv = act ? vv : vc;
-            cB[j] = vv;
-            L(sk, 0, li[j]) = vv;
-            if (reduce) {
-              const bool own = act && zown && (fl[j] & (q ? MGX_F_OWN1 : MGX_F_OWN0)) != 0;
-              const T d = vv - vc;
-              const T d2 = own ? d * d : (T)0;
-              err = d2 > err ? d2 : err;
-              if (reduce & 2) mgx_exact_add_nb(slo, shi, own ? (double)(vv < (T)0 ? -vv : vv) : 0.0, ovf);
-            }
+          const int q = (iy[j] + zg) & 1;                   // position of the odd cell in the pair
+          other[j] = L(sk, 1, li[j] + (2 * q - 1));
+          vym[j] = L(sk, 1, li[j] - LP);
+          vyp[j] = L(sk, 1, li[j] + LP);
+        }
+#pragma unroll
+        for (int j = 0; j < R; ++j) {
+          const int q = (iy[j] + zg) & 1;
+          actv[j] = (fl[j] & (q ? MGX_F_BLK1 : MGX_F_BLK0)) != 0;
+          const T vc = cB[j], partner = cR[j];
+          T vv;
+          if (BOXES) {
+            const unsigned X0 = q ? mx[j][2] : mx[j][1], Xm = q ? mx[j][1] : mx[j][0], Xp = q ? mx[j][3] : mx[j][2];
+            const unsigned XY = X0 & my[j][1];
+            vv = mgx_cell_new_sets<T>(vc, q ? partner : other[j], q ? other[j] : partner, vym[j], vyp[j], mR[j], nR[j],
+                                      XY & z0s, Xm & my[j][1] & z0s, Xp & my[j][1] & z0s, X0 & my[j][0] & z0s,
+                                      X0 & my[j][2] & z0s, XY & zm, XY & zp, cmask, rmask, bl->rho, p);
+          } else {
+            // x-1 and x+1 carry the same weight and a*w + b*w commutes exactly: no need to order them
+#ifdef MGX_ABLATE_COMPUTE
+            vv = vc + other[j] + vym[j] + vyp[j] + mR[j] + nR[j] + partner;
+#else
+            vv = p.s1 * vc + p.s2 * mgx_avg_uniform<T>(partner, other[j], vym[j], vyp[j], mR[j], nR[j], p.w);
+#endif
+          }
+          vold[j] = vc;
+          cB[j] = actv[j] ? vv : vc;
+        }
+#pragma unroll
+        for (int j = 0; j < R; ++j) L(sk, 0, li[j]) = cB[j];
+        if (reduce) {
+#pragma unroll
+          for (int j = 0; j < R; ++j) {
+            const int q = (iy[j] + zg) & 1;
+            const bool own = actv[j] && zown && (fl[j] & (q ? MGX_F_OWN1 : MGX_F_OWN0)) != 0;
+            const T d = cB[j] - vold[j];
+            const T d2 = own ? d * d : (T)0;
+            err = d2 > err ? d2 : err;
+            if (reduce & 2) mgx_exact_add_nb(slo, shi, own ? (double)(cB[j] < (T)0 ? -cB[j] : cB[j]) : 0.0, ovf);
           }
         }
       }
       make_zsets(zg + 1, (k + 1) & 1);                      // for the next step; this step reads the other parity
-      __syncthreads();
+      MGX_SYNC();
 
       // ---------------- red cells of plane k-1; store the finished plane ----------------
-      if (k - 1 >= zc0 && wave < 4) {
+      if (k - 1 >= zc0 && wave < NW) {
         const int kr = k - 1, zgr = kr + g.z0;
         const long long pb = pzl * (kr + 1);
+        T other[R], vym[R], vyp[R], vold[R];
+        bool actv[R];
 #pragma unroll
         for (int j = 0; j < R; ++j) {
-          if (rowf[j] & MGX_F_RED0) {
-            const int q = (1 + iy[j] + zgr) & 1;            // position of the even cell in the pair
-            const bool act = (fl[j] & (q ? MGX_F_RED1 : MGX_F_RED0)) != 0;
-            const T vc = mR[j], partner = mB[j];
-            const T other = L(sm, 0, li[j] + (2 * q - 1));
-            const T vym = L(sm, 0, li[j] - LP), vyp = L(sm, 0, li[j] + LP);
-            const T vzp = cB[j];
-            T vv;
-            if (BOXES) {
-              const unsigned X0 = q ? mx[j][2] : mx[j][1], Xm = q ? mx[j][1] : mx[j][0], Xp = q ? mx[j][3] : mx[j][2];
-              const unsigned XY = X0 & my[j][1];
-              vv = mgx_cell_new_sets<T>(vc, q ? partner : other, q ? other : partner, vym, vyp, below[j], vzp, XY & zm,
-                                        Xm & my[j][1] & zm, Xp & my[j][1] & zm, X0 & my[j][0] & zm,
-                                        X0 & my[j][2] & zm, XY & zmm, XY & z0s, cmask, rmask, bl->rho, p);
-            } else {
-              vv = p.s1 * vc + p.s2 * mgx_avg_uniform<T>(partner, other, vym, vyp, below[j], vzp, p.w);
-            }
-            vv = act ? vv : vc;
-            if (reduce) {
-              const T d = vv - vc;
-              const T d2 = act ? d * d : (T)0;
-              err = d2 > err ? d2 : err;
-              if (reduce & 2) mgx_exact_add_nb(slo, shi, act ? (double)(vv < (T)0 ? -vv : vv) : 0.0, ovf);
-            }
-            V2 out;
-            out.x = q ? partner : vv;
-            out.y = q ? vv : partner;
-            *reinterpret_cast<V2 *>(dst + (gst[j] >= 0 ? pb + gst[j] : 0)) = out;
+          const int q = (1 + iy[j] + zgr) & 1;              // position of the even cell in the pair
+          other[j] = L(sm, 0, li[j] + (2 * q - 1));
+          vym[j] = L(sm, 0, li[j] - LP);
+          vyp[j] = L(sm, 0, li[j] + LP);
+        }
+#pragma unroll
+        for (int j = 0; j < R; ++j) {
+          const int q = (1 + iy[j] + zgr) & 1;
+          actv[j] = (fl[j] & (q ? MGX_F_RED1 : MGX_F_RED0)) != 0;
+          const T vc = mR[j], partner = mB[j];
+          T vv;
+          if (BOXES) {
+            const unsigned X0 = q ? mx[j][2] : mx[j][1], Xm = q ? mx[j][1] : mx[j][0], Xp = q ? mx[j][3] : mx[j][2];
+            const unsigned XY = X0 & my[j][1];
+            vv = mgx_cell_new_sets<T>(vc, q ? partner : other[j], q ? other[j] : partner, vym[j], vyp[j], below[j], cB[j],
+                                      XY & zm, Xm & my[j][1] & zm, Xp & my[j][1] & zm, X0 & my[j][0] & zm,
+                                      X0 & my[j][2] & zm, XY & zmm, XY & z0s, cmask, rmask, bl->rho, p);
+          } else {
+#ifdef MGX_ABLATE_COMPUTE
+            vv = vc + other[j] + vym[j] + vyp[j] + below[j] + cB[j] + partner;
+#else
+            vv = p.s1 * vc + p.s2 * mgx_avg_uniform<T>(partner, other[j], vym[j], vyp[j], below[j], cB[j], p.w);
+#endif
+          }
+          vold[j] = vc;
+          mR[j] = actv[j] ? vv : vc;
+          V2 out;
+          out.x = q ? partner : mR[j];
+          out.y = q ? mR[j] : partner;
+          *reinterpret_cast<V2 *>(dst + (gst[j] >= 0 ? pb + gst[j] : 0)) = out;
+        }
+        if (reduce) {
+#pragma unroll
+          for (int j = 0; j < R; ++j) {
+            const T d = mR[j] - vold[j];
+            const T d2 = actv[j] ? d * d : (T)0;
+            err = d2 > err ? d2 : err;
+            if (reduce & 2) mgx_exact_add_nb(slo, shi, actv[j] ? (double)(mR[j] < (T)0 ? -mR[j] : mR[j]) : 0.0, ovf);
           }
         }
       }
@@ -340,19 +374,20 @@ __device__ inline void mgx_fused_body(const T *__restrict__ src, T *__restrict__
       for (int j = 0; j < R; ++j) below[j] = mB[j];
       sk = sp;
       zmm = zm;                                             // Z set of plane k-1 = (k+1)-2 for the next red phase
-      __syncthreads();
+      MGX_SYNC();
     }
   }
 #undef MGX_FETCH
+#undef MGX_COLOUR
 #undef MGX_STAGE
 
-  if (reduce) mgx_block_commit<5>((double)err, slo, shi, ovf, reduce, res);
+  if (reduce) mgx_block_commit<NW + 1>((double)err, slo, shi, ovf, reduce, res);
 }
 
 // One launch per tile class: `tiles` lists the tiles (x fastest, then y, then z chunk) that boxes do not
 // reach (BOXES = false) or do reach (BOXES = true); the host builds both lists from the box table.
-template <typename T, int TY, bool BOXES, int D>
-__global__ __launch_bounds__(320) void k_fused_sweep(const T *__restrict__ src, T *__restrict__ dst, const MgxGeom g,
+template <typename T, int TY, bool BOXES, int NW>
+__global__ __launch_bounds__((NW + 1) * 64) void k_fused_sweep(const T *__restrict__ src, T *__restrict__ dst, const MgxGeom g,
                                                      const MgxSweepParams<T> p, const MgxBox *__restrict__ bx,
                                                      const int nb, const int ZC, const int ntx, const int nty,
                                                      const int *__restrict__ tiles, const int reduce,
@@ -372,21 +407,22 @@ __global__ __launch_bounds__(320) void k_fused_sweep(const T *__restrict__ src, 
   const int tx = lid % ntx, ty = (lid / ntx) % nty, tz = lid / (ntx * nty);
   const int tx0 = 1 + tx * 2 * TXP, ty0 = 1 + ty * TY;
   const int zc0 = 1 + tz * ZC, zc1 = min(zc0 + ZC - 1, g.n3);
-  mgx_fused_body<T, TY, BOXES, D>(src, dst, g, p, bx, nb, tx0, ty0, zc0, zc1, reduce, res, lds, bl);
+  mgx_fused_body<T, TY, BOXES, NW>(src, dst, g, p, bx, nb, tx0, ty0, zc0, zc1, reduce, res, lds, bl);
 }
 
 // ------------------------------------------------------------------------------------------------
 // host side
 
 struct MgxFusedPlan {            // per level: tile decomposition and the two tile lists (device)
-  int ty = 0, ZC = 0, ntx = 0, nty = 0, nzc = 0;
+  int ty = 0, nw = 4, ZC = 0, ntx = 0, nty = 0, nzc = 0;
   int n_fast = 0, n_box = 0;
   int *d_tiles = nullptr;        // n_fast entries, then n_box entries
   bool valid = false;
 };
 
-static int mgx_fused_ty = 8;     // tile height selector (8, 12 or 16), settable for benchmarking
-static int mgx_fused_depth = 1;  // planes fetched ahead of their first use (1 or 2)
+static int mgx_fused_ty = 0;     // tile height override (0 = automatic), settable for benchmarking
+static int mgx_fused_nw = 0;     // row waves per block override (4 or 8)
+static int mgx_fused_zc = 0;     // z chunk override (0 = automatic)
 
 // (re)build the plan: which tiles can any box reach?  A tile asks about cells of its footprint grown by
 // one and about their neighbours, i.e. positions grown by two, on planes zc0-2 .. zc1+2.
@@ -394,14 +430,20 @@ static int mgx_fused_make_plan(MgxFusedPlan &pl, const MgxGeom &g, const std::ve
   constexpr int TXP = 64;
   if (pl.d_tiles) { (void)hipFree(pl.d_tiles); pl.d_tiles = nullptr; }
   pl.valid = false;
-  pl.ty = (mgx_fused_ty == 16 || mgx_fused_ty == 12) ? mgx_fused_ty : 8;
+  // 128 x 20 tiles on 8 row waves measured fastest on large levels; small levels take the small tile
+  if (g.n1 >= 96 && g.n2 >= 40) { pl.ty = 20; pl.nw = 8; } else { pl.ty = 8; pl.nw = 4; }
+  if (mgx_fused_ty > 0) {
+    const int want = mgx_fused_ty * 100 + mgx_fused_nw;
+    if (want == 804 || want == 1604 || want == 1204 || want == 1208 || want == 2008 || want == 2808) { pl.ty = mgx_fused_ty; pl.nw = mgx_fused_nw; }
+  }
   pl.ntx = (g.n1 + 2 * TXP - 1) / (2 * TXP);
   pl.nty = (g.n2 + pl.ty - 1) / pl.ty;
   // z chunk: enough blocks to fill 256 CUs several times over, but at least 16 planes per chunk so
   // that the extra planes a chunk fetches stay cheap
   int ZC = g.n3;
   const long long per_chunk = (long long)pl.ntx * pl.nty;
-  while (ZC > 16 && per_chunk * ((g.n3 + ZC - 1) / ZC) < 4096) ZC = (ZC + 1) / 2;
+  while (ZC > 32 && per_chunk * ((g.n3 + ZC - 1) / ZC) < 2048) ZC = (ZC + 1) / 2;
+  if (mgx_fused_zc > 0) ZC = std::min(mgx_fused_zc, g.n3);
   pl.ZC = ZC;
   pl.nzc = (g.n3 + ZC - 1) / ZC;
   const long long ntile = per_chunk * pl.nzc;
@@ -429,23 +471,23 @@ static int mgx_fused_make_plan(MgxFusedPlan &pl, const MgxGeom &g, const std::ve
   return 0;
 }
 
-template <typename T, int TY, int D>
+template <typename T, int TY, int NW>
 static int mgx_fused_launch_cfg(const MgxFusedPlan &pl, const T *src, T *dst, const MgxGeom &g, const MgxSweepParams<T> &p,
                                 const MgxBox *bx, int nb, int reduce, u64 *res, hipStream_t st) {
   constexpr int TXP = 64;
   constexpr size_t lds = (size_t)3 * 2 * (TXP + 2) * (TY + 6) * sizeof(T) + sizeof(MgxBoxLds<T>);
   if (lds > 64 * 1024) {      // beyond the default dynamic LDS limit: raise it for both kernels
-    if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_fused_sweep<T, TY, false, D>),
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_fused_sweep<T, TY, false, NW>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
-        hipFuncSetAttribute(reinterpret_cast<const void *>(k_fused_sweep<T, TY, true, D>),
+        hipFuncSetAttribute(reinterpret_cast<const void *>(k_fused_sweep<T, TY, true, NW>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
       return -1;
   }
   if (pl.n_fast > 0)
-    hipLaunchKernelGGL((k_fused_sweep<T, TY, false, D>), dim3((unsigned)pl.n_fast), dim3(320), lds, st, src, dst, g, p, bx, nb,
+    hipLaunchKernelGGL((k_fused_sweep<T, TY, false, NW>), dim3((unsigned)pl.n_fast), dim3((NW + 1) * 64), lds, st, src, dst, g, p, bx, nb,
                        pl.ZC, pl.ntx, pl.nty, pl.d_tiles, reduce, res);
   if (pl.n_box > 0)
-    hipLaunchKernelGGL((k_fused_sweep<T, TY, true, D>), dim3((unsigned)pl.n_box), dim3(320), lds, st, src, dst, g, p, bx, nb,
+    hipLaunchKernelGGL((k_fused_sweep<T, TY, true, NW>), dim3((unsigned)pl.n_box), dim3((NW + 1) * 64), lds, st, src, dst, g, p, bx, nb,
                        pl.ZC, pl.ntx, pl.nty, pl.d_tiles + pl.n_fast, reduce, res);
   return 0;
 }
@@ -459,16 +501,12 @@ static bool mgx_fused_supported(const MgxGeom &g, int nbox) {
 template <typename T>
 static int mgx_fused_launch(const MgxFusedPlan &pl, const T *src, T *dst, const MgxGeom &g, const MgxSweepParams<T> &p,
                             const MgxBox *bx, int nb, int reduce, u64 *res, hipStream_t st) {
-  if (mgx_fused_depth == 2) {
-    switch (pl.ty) {
-      case 16: return mgx_fused_launch_cfg<T, 16, 2>(pl, src, dst, g, p, bx, nb, reduce, res, st);
-      case 12: return mgx_fused_launch_cfg<T, 12, 2>(pl, src, dst, g, p, bx, nb, reduce, res, st);
-      default: return mgx_fused_launch_cfg<T, 8, 2>(pl, src, dst, g, p, bx, nb, reduce, res, st);
-    }
-  }
-  switch (pl.ty) {
-    case 16: return mgx_fused_launch_cfg<T, 16, 1>(pl, src, dst, g, p, bx, nb, reduce, res, st);
-    case 12: return mgx_fused_launch_cfg<T, 12, 1>(pl, src, dst, g, p, bx, nb, reduce, res, st);
-    default: return mgx_fused_launch_cfg<T, 8, 1>(pl, src, dst, g, p, bx, nb, reduce, res, st);
+  switch (pl.ty * 100 + pl.nw) {
+    case 1604: return mgx_fused_launch_cfg<T, 16, 4>(pl, src, dst, g, p, bx, nb, reduce, res, st);
+    case 1204: return mgx_fused_launch_cfg<T, 12, 4>(pl, src, dst, g, p, bx, nb, reduce, res, st);
+    case 1208: return mgx_fused_launch_cfg<T, 12, 8>(pl, src, dst, g, p, bx, nb, reduce, res, st);
+    case 2008: return mgx_fused_launch_cfg<T, 20, 8>(pl, src, dst, g, p, bx, nb, reduce, res, st);
+    case 2808: return mgx_fused_launch_cfg<T, 28, 8>(pl, src, dst, g, p, bx, nb, reduce, res, st);
+    default: return mgx_fused_launch_cfg<T, 8, 4>(pl, src, dst, g, p, bx, nb, reduce, res, st);
   }
 }

@@ -12,7 +12,7 @@ from typing import Optional, Sequence, Tuple
 import numpy as np
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libmgx.so")
+LIB_PATH = os.environ.get("MGX_LIB") or os.path.join(_HERE, "libmgx.so")
 
 RED_ERR, RED_SUM = 1, 2
 KERNEL_AUTO, KERNEL_TWO_PASS, KERNEL_FUSED = 0, 1, 2
