@@ -52,6 +52,8 @@ struct mgx_ctx {
   bool own_stream = false;
   int kernel = MGX_KERNEL_AUTO;
   u64 *h_res = nullptr;        // pinned read-back buffer
+  hipStream_t aux = nullptr;   // side stream: box tiles of the fused sweep run beside the others
+  hipEvent_t ev_fork = nullptr, ev_join = nullptr;
 };
 
 struct mgx_level {
@@ -128,6 +130,12 @@ extern "C" int mgx_ctx_create(int device, void *stream, mgx_ctx **out) {
   }
   hipError_t e = hipHostMalloc((void **)&c->h_res, MGX_RES_WORDS * sizeof(u64), hipHostMallocDefault);
   if (e != hipSuccess) { delete c; return fail(MGX_EHIP, "hipHostMalloc: %s", hipGetErrorString(e)); }
+  if (hipStreamCreateWithFlags(&c->aux, hipStreamNonBlocking) != hipSuccess ||
+      hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess ||
+      hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess) {
+    delete c;
+    return fail(MGX_EHIP, "mgx_ctx_create: side stream / events");
+  }
   *out = c;
   return MGX_OK;
 }
@@ -136,6 +144,9 @@ extern "C" int mgx_ctx_destroy(mgx_ctx *ctx) {
   if (!ctx) return MGX_OK;
   (void)hipSetDevice(ctx->device);
   (void)hipStreamSynchronize(ctx->stream);
+  if (ctx->aux) { (void)hipStreamSynchronize(ctx->aux); (void)hipStreamDestroy(ctx->aux); }
+  if (ctx->ev_fork) (void)hipEventDestroy(ctx->ev_fork);
+  if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
   if (ctx->h_res) (void)hipHostFree(ctx->h_res);
   delete ctx;
@@ -381,7 +392,8 @@ static int do_sweeps(mgx_level *lv, int nsweeps, int reduce) {
       if (!lv->plan.valid && mgx_fused_make_plan(lv->plan, g, lv->boxes, C(lv)->stream) != 0)
         return fail(MGX_EHIP, "mgx_level_sweep: could not build the tile lists of the fused kernel");
       if (mgx_fused_launch<T>(lv->plan, (const T *)lv->buf[lv->cur], (T *)lv->buf[1 - lv->cur], g, make_params<T>(lv),
-                              lv->d_boxes, lv->nbox, red, lv->d_res, C(lv)->stream) != 0)
+                              lv->d_boxes, lv->nbox, red, lv->d_res, C(lv)->stream, C(lv)->aux, C(lv)->ev_fork,
+                              C(lv)->ev_join) != 0)
         return fail(MGX_EHIP, "mgx_level_sweep: fused kernel launch configuration failed");
       HIP_TRY(hipGetLastError());
       lv->cur = 1 - lv->cur;

@@ -58,6 +58,7 @@ template <typename T>
 struct MgxBoxLds {           // per-block copy of what the box body needs
   unsigned zsets[2][4];      // [step parity][plane k-1, k, k+1, unused]
   T rho[MGX_MAX_FUSED_BOXES + 1];   // rho of box b; slot 32 = 1 (no box)
+  T win[MGX_MAX_FUSED_BOXES + 1][3]; // weights of a cell whose six neighbours all have box b first (slot 32: none)
 };
 
 // new value of one cell in a tile that boxes reach.  sets: boxes containing the cell (c) and its six
@@ -66,8 +67,9 @@ template <typename T>
 __device__ inline T mgx_cell_new_sets(const T vc, const T vxm, const T vxp, const T vym, const T vyp, const T vzm,
                                       const T vzp, const unsigned sc, const unsigned sxm, const unsigned sxp,
                                       const unsigned sym, const unsigned syp, const unsigned szm, const unsigned szp,
-                                      const unsigned cmask, const unsigned rmask, const T *__restrict__ rho,
+                                      const unsigned cmask, const unsigned rmask, const MgxBoxLds<T> *__restrict__ bl,
                                       const MgxSweepParams<T> &p) {
+  const T *__restrict__ rho = bl->rho;
   T avg;
   if (sc & cmask) {
     avg = vc;                                            // val returns V itself (m_gs_CDS.F90:726-727)
@@ -77,6 +79,15 @@ __device__ inline T mgx_cell_new_sets(const T vc, const T vxm, const T vxp, cons
                    fz = szm & (0u - szm), fzp = szp & (0u - szp);
     if (((fx | fxp | fy | fyp | fz | fzp) & rmask) == 0) {
       avg = mgx_avg_uniform<T>(vxm, vxp, vym, vyp, vzm, vzp, p.w);
+    } else if (fx == fxp && fx == fy && fx == fyp && fx == fz && fx == fzp) {
+      // all six neighbours have the same first box: its weights were made once per block with the very
+      // arithmetic of the general branch below (rho*a, sequential sum, six divisions)
+      const T *w = bl->win[__ffs((int)fx) - 1];
+      avg = vxm * w[0] + vxp * w[0];
+      avg = avg + vym * w[1];
+      avg = avg + vyp * w[1];
+      avg = avg + vzm * w[2];
+      avg = avg + vzp * w[2];
     } else {
       T r[6];
       r[0] = rho[sxm ? __ffs((int)sxm) - 1 : 32] * p.a[0];
@@ -188,7 +199,16 @@ __device__ inline void mgx_fused_body(const T *__restrict__ src, T *__restrict__
       rmask |= bx[b].rho_is_one ? 0u : (1u << b);
     }
     if (wave == NW && lane < nb) { blo2 = bx[lane].lo[2]; bhi2 = bx[lane].hi[2]; }
-    if (threadIdx.x <= MGX_MAX_FUSED_BOXES) bl->rho[threadIdx.x] = threadIdx.x < nb ? (T)bx[threadIdx.x].rho : (T)1;
+    if (threadIdx.x <= MGX_MAX_FUSED_BOXES) {
+      const T rb = threadIdx.x < nb ? (T)bx[threadIdx.x].rho : (T)1;
+      bl->rho[threadIdx.x] = rb;
+      T r[6] = {rb * p.a[0], rb * p.a[0], rb * p.a[1], rb * p.a[1], rb * p.a[2], rb * p.a[2]};
+      T s = r[0];
+      s = s + r[1]; s = s + r[2]; s = s + r[3]; s = s + r[4]; s = s + r[5];
+      bl->win[threadIdx.x][0] = r[0] / s;
+      bl->win[threadIdx.x][1] = r[2] / s;
+      bl->win[threadIdx.x][2] = r[4] / s;
+    }
   }
   // Z sets for planes zz-1, zz, zz+1 (global), written by wave 4 into parity slot `par`
   auto make_zsets = [&](int zz, int par) {
@@ -289,7 +309,7 @@ __device__ inline void mgx_fused_body(const T *__restrict__ src, T *__restrict__
             const unsigned XY = X0 & my[j][1];
             vv = mgx_cell_new_sets<T>(vc, q ? partner : other[j], q ? other[j] : partner, vym[j], vyp[j], mR[j], nR[j],
                                       XY & z0s, Xm & my[j][1] & z0s, Xp & my[j][1] & z0s, X0 & my[j][0] & z0s,
-                                      X0 & my[j][2] & z0s, XY & zm, XY & zp, cmask, rmask, bl->rho, p);
+                                      X0 & my[j][2] & z0s, XY & zm, XY & zp, cmask, rmask, bl, p);
           } else {
             // x-1 and x+1 carry the same weight and a*w + b*w commutes exactly: no need to order them
 #ifdef MGX_ABLATE_COMPUTE
@@ -342,7 +362,7 @@ __device__ inline void mgx_fused_body(const T *__restrict__ src, T *__restrict__
             const unsigned XY = X0 & my[j][1];
             vv = mgx_cell_new_sets<T>(vc, q ? partner : other[j], q ? other[j] : partner, vym[j], vyp[j], below[j], cB[j],
                                       XY & zm, Xm & my[j][1] & zm, Xp & my[j][1] & zm, X0 & my[j][0] & zm,
-                                      X0 & my[j][2] & zm, XY & zmm, XY & z0s, cmask, rmask, bl->rho, p);
+                                      X0 & my[j][2] & zm, XY & zmm, XY & z0s, cmask, rmask, bl, p);
           } else {
 #ifdef MGX_ABLATE_COMPUTE
             vv = vc + other[j] + vym[j] + vyp[j] + below[j] + cB[j] + partner;
@@ -473,7 +493,8 @@ static int mgx_fused_make_plan(MgxFusedPlan &pl, const MgxGeom &g, const std::ve
 
 template <typename T, int TY, int NW>
 static int mgx_fused_launch_cfg(const MgxFusedPlan &pl, const T *src, T *dst, const MgxGeom &g, const MgxSweepParams<T> &p,
-                                const MgxBox *bx, int nb, int reduce, u64 *res, hipStream_t st) {
+                                const MgxBox *bx, int nb, int reduce, u64 *res, hipStream_t st, hipStream_t aux, hipEvent_t ev_fork,
+                                hipEvent_t ev_join) {
   constexpr int TXP = 64;
   constexpr size_t lds = (size_t)3 * 2 * (TXP + 2) * (TY + 6) * sizeof(T) + sizeof(MgxBoxLds<T>);
   if (lds > 64 * 1024) {      // beyond the default dynamic LDS limit: raise it for both kernels
@@ -483,12 +504,21 @@ static int mgx_fused_launch_cfg(const MgxFusedPlan &pl, const T *src, T *dst, co
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
       return -1;
   }
+  // The (few, slower) tiles that boxes reach run on the side stream, concurrently with the others.
+  const bool side = pl.n_box > 0 && pl.n_fast > 0 && aux != nullptr;
+  hipStream_t sb = side ? aux : st;
+  if (side) {
+    if (hipEventRecord(ev_fork, st) != hipSuccess || hipStreamWaitEvent(aux, ev_fork, 0) != hipSuccess) return -1;
+  }
+  if (pl.n_box > 0)
+    hipLaunchKernelGGL((k_fused_sweep<T, TY, true, NW>), dim3((unsigned)pl.n_box), dim3((NW + 1) * 64), lds, sb, src, dst, g, p, bx, nb,
+                       pl.ZC, pl.ntx, pl.nty, pl.d_tiles + pl.n_fast, reduce, res);
   if (pl.n_fast > 0)
     hipLaunchKernelGGL((k_fused_sweep<T, TY, false, NW>), dim3((unsigned)pl.n_fast), dim3((NW + 1) * 64), lds, st, src, dst, g, p, bx, nb,
                        pl.ZC, pl.ntx, pl.nty, pl.d_tiles, reduce, res);
-  if (pl.n_box > 0)
-    hipLaunchKernelGGL((k_fused_sweep<T, TY, true, NW>), dim3((unsigned)pl.n_box), dim3((NW + 1) * 64), lds, st, src, dst, g, p, bx, nb,
-                       pl.ZC, pl.ntx, pl.nty, pl.d_tiles + pl.n_fast, reduce, res);
+  if (side) {
+    if (hipEventRecord(ev_join, aux) != hipSuccess || hipStreamWaitEvent(st, ev_join, 0) != hipSuccess) return -1;
+  }
   return 0;
 }
 
@@ -500,13 +530,14 @@ static bool mgx_fused_supported(const MgxGeom &g, int nbox) {
 
 template <typename T>
 static int mgx_fused_launch(const MgxFusedPlan &pl, const T *src, T *dst, const MgxGeom &g, const MgxSweepParams<T> &p,
-                            const MgxBox *bx, int nb, int reduce, u64 *res, hipStream_t st) {
+                            const MgxBox *bx, int nb, int reduce, u64 *res, hipStream_t st, hipStream_t aux,
+                            hipEvent_t ev_fork, hipEvent_t ev_join) {
   switch (pl.ty * 100 + pl.nw) {
-    case 1604: return mgx_fused_launch_cfg<T, 16, 4>(pl, src, dst, g, p, bx, nb, reduce, res, st);
-    case 1204: return mgx_fused_launch_cfg<T, 12, 4>(pl, src, dst, g, p, bx, nb, reduce, res, st);
-    case 1208: return mgx_fused_launch_cfg<T, 12, 8>(pl, src, dst, g, p, bx, nb, reduce, res, st);
-    case 2008: return mgx_fused_launch_cfg<T, 20, 8>(pl, src, dst, g, p, bx, nb, reduce, res, st);
-    case 2808: return mgx_fused_launch_cfg<T, 28, 8>(pl, src, dst, g, p, bx, nb, reduce, res, st);
-    default: return mgx_fused_launch_cfg<T, 8, 4>(pl, src, dst, g, p, bx, nb, reduce, res, st);
+    case 1604: return mgx_fused_launch_cfg<T, 16, 4>(pl, src, dst, g, p, bx, nb, reduce, res, st, aux, ev_fork, ev_join);
+    case 1204: return mgx_fused_launch_cfg<T, 12, 4>(pl, src, dst, g, p, bx, nb, reduce, res, st, aux, ev_fork, ev_join);
+    case 1208: return mgx_fused_launch_cfg<T, 12, 8>(pl, src, dst, g, p, bx, nb, reduce, res, st, aux, ev_fork, ev_join);
+    case 2008: return mgx_fused_launch_cfg<T, 20, 8>(pl, src, dst, g, p, bx, nb, reduce, res, st, aux, ev_fork, ev_join);
+    case 2808: return mgx_fused_launch_cfg<T, 28, 8>(pl, src, dst, g, p, bx, nb, reduce, res, st, aux, ev_fork, ev_join);
+    default: return mgx_fused_launch_cfg<T, 8, 4>(pl, src, dst, g, p, bx, nb, reduce, res, st, aux, ev_fork, ev_join);
   }
 }
