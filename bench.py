@@ -136,6 +136,7 @@ def main():
     ap.add_argument("--vcycle-tol", default="1.e-8")
     ap.add_argument("--sor", default="1.7")
     ap.add_argument("--kernel", type=int, default=0, help="0 auto, 1 two-pass, 2 fused")
+    ap.add_argument("--own-stream", action="store_true", help="let the library create its stream (events then see nothing)")
     args = ap.parse_args()
 
     import torch
@@ -161,7 +162,7 @@ def main():
     # events below bracket exactly the kernels of the timed region
     tstream = torch.cuda.Stream()
     torch.cuda.set_stream(tstream)
-    ctx = lib.Context(local_rank, tstream.cuda_stream)
+    ctx = lib.Context(local_rank, None if args.own_stream else tstream.cuda_stream)
     ctx.set_kernel(args.kernel)
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 

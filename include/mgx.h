@@ -112,7 +112,7 @@ int mgx_level_result_reset(mgx_level *lv);
 int mgx_level_result(mgx_level *lv, double *err_sq_max, double *abs_sum, uint64_t sum_limbs[2]);
 
 /* grid_sum (t_mg.f90:794-814), call sites m_gs_CDS.F90:136,149,195,206,238,245,269,275.
- * Defined order-independently: sum of floor(|V|*2^72) as a 128-bit integer,
+ * Defined order-independently: sum of rne(|V|*2^72) (nearest-even) as a 128-bit integer,
  * rounded once to double — the same bits for any tiling or GPU count. [sync] */
 int mgx_level_abs_sum(mgx_level *lv, double *sum);
 int mgx_level_abs_sum_limbs(mgx_level *lv, uint64_t limbs[2]);    /* [sync] low, high word */

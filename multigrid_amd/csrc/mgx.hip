@@ -201,11 +201,11 @@ extern "C" int mgx_level_create_slab(mgx_ctx *ctx, int layer, const int32_t n[3]
       return fail(MGX_ENOMEM, "mgx_level_create: hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
     }
   }
-  hipError_t e = hipMalloc((void **)&lv->d_res, MGX_RES_WORDS * sizeof(u64));
+  hipError_t e = hipMalloc((void **)&lv->d_res, MGX_RES_WORDS * (1 + MGX_RES_SLOTS) * sizeof(u64));
   if (e != hipSuccess) { (void)hipFree(lv->buf[0]); (void)hipFree(lv->buf[1]); delete lv; return fail(MGX_ENOMEM, "hipMalloc(result)"); }
   HIP_TRY(hipMemsetAsync(lv->buf[0], 0, bytes, ctx->stream));
   HIP_TRY(hipMemsetAsync(lv->buf[1], 0, bytes, ctx->stream));
-  HIP_TRY(hipMemsetAsync(lv->d_res, 0, MGX_RES_WORDS * sizeof(u64), ctx->stream));
+  HIP_TRY(hipMemsetAsync(lv->d_res, 0, MGX_RES_WORDS * (1 + MGX_RES_SLOTS) * sizeof(u64), ctx->stream));
   lv->shell_synced = true;
   lv->defined = true;
   *out = lv;
@@ -343,7 +343,7 @@ extern "C" int mgx_level_setup(mgx_level *lv, int init) {
 // sweeps
 
 static int reset_result(mgx_level *lv) {
-  HIP_TRY(hipMemsetAsync(lv->d_res, 0, MGX_RES_WORDS * sizeof(u64), C(lv)->stream));
+  HIP_TRY(hipMemsetAsync(lv->d_res, 0, MGX_RES_WORDS * (1 + MGX_RES_SLOTS) * sizeof(u64), C(lv)->stream));
   return MGX_OK;
 }
 
@@ -442,6 +442,8 @@ extern "C" double mgx_limbs_to_double(const uint64_t limbs[2]) {
 
 static int fetch_result(mgx_level *lv, double *err, double *sum, uint64_t limbs_out[2]) {
   mgx_ctx *c = C(lv);
+  hipLaunchKernelGGL(k_fold_result, dim3(1), dim3(MGX_RES_SLOTS), 0, c->stream, lv->d_res);
+  HIP_TRY(hipGetLastError());
   HIP_TRY(hipMemcpyAsync(c->h_res, lv->d_res, MGX_RES_WORDS * sizeof(u64), hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
   const u64 *r = c->h_res;

@@ -44,7 +44,7 @@ struct MgxSweepParams {
 };
 
 // ---- exact |V| accumulation -------------------------------------------------------------------
-// acc += floor(|v| * 2^72) in 128 bits.  |v| >= 2^20 or non-finite raises ovf (the sum of 2^34
+// acc += rne(|v| * 2^72) (round to nearest, ties to even) in 128 bits.  |v| >= 2^20 or non-finite raises ovf (the sum of 2^34
 // such cells would no longer fit).  Pure integer arithmetic: any association gives the same bits.
 #define MGX_SUM_Q 72
 
@@ -66,11 +66,50 @@ __host__ __device__ inline void mgx_exact_add(u64 &lo, u64 &hi, double a, unsign
     alo = m << sh;
     ahi = (m >> 1) >> (63 - sh);
   } else {
-    alo = (sh > -64) ? (m >> (-sh)) : 0ull;
+    if (sh > -64) {
+      const int r = -sh;
+      const u64 rem = m & ((1ull << r) - 1), half = 1ull << (r - 1);
+      alo = m >> r;
+      alo += (rem > half || (rem == half && (alo & 1))) ? 1ull : 0ull;
+    } else {
+      alo = 0ull;
+    }
     ahi = 0ull;
   }
   lo += alo;
   hi += ahi + (lo < alo ? 1ull : 0ull);
+}
+
+// ---- the same sum at fp64-VALU cost ------------------------------------------------------------
+// For a in [0, 2^11): hi = (a + 2^20) - 2^20 is a rounded (nearest-even) to a multiple of 2^-32, lo = a - hi
+// is exact with |lo| <= 2^-33, and (lo + 1.5*2^-20) - 1.5*2^-20 is lo rounded (nearest-even) to a multiple
+// of 2^-72; hi is a multiple of 2^-32, so hi + that is rne(a * 2^72) * 2^-72.  Partial sums of at most
+// MGX_FAST_SUM_CELLS such terms stay exact in two doubles (sum of hi < 2^21: 53 bits above 2^-32; |sum of
+// lo| < 2^-19: 53 bits above 2^-72); mgx_fast_sum_flush moves them into the 128-bit integer.  The build
+// keeps IEEE semantics (no contraction, no fast-math), so the compiler does not fold (a + c) - c.
+#define MGX_FAST_SUM_LIMIT 2048.0
+#define MGX_FAST_SUM_CELLS 1023
+
+__device__ inline void mgx_fast_sum_add(double &h, double &l, const double a) {
+  const double c1 = 1048576.0;                       // 2^20
+  const double c2 = 1.5 / 1048576.0;                 // 1.5 * 2^-20
+  const double hi = (a + c1) - c1;
+  const double lo = a - hi;
+  h = h + hi;
+  l = l + ((lo + c2) - c2);
+}
+
+__device__ inline void mgx_fast_sum_flush(double &h, double &l, u64 &lo, u64 &hi) {
+  const u64 hq = (u64)(h * 4294967296.0);            // < 2^53, units of 2^-32
+  const long long lq = (long long)(l * 4722366482869645213696.0);   // |.| < 2^53, units of 2^-72
+  const u64 alo = hq << 40, ahi = hq >> 24;
+  lo += alo;
+  hi += ahi + (lo < alo ? 1ull : 0ull);
+  const u64 blo = (u64)lq;
+  lo += blo;
+  hi += (lq < 0 ? ~0ull : 0ull) + (lo < blo ? 1ull : 0ull);
+  h = 0.0;
+  l = 0.0;
 }
 
 // The device-side result record of a level (u64 words):
@@ -78,3 +117,6 @@ __host__ __device__ inline void mgx_exact_add(u64 &lo, u64 &hi, double a, unsign
 //   [1..4] the 128-bit sum as four 32-bit digits kept in 64-bit words (carries deferred)
 //   [5] overflow flag of the sum
 #define MGX_RES_WORDS 8
+// Blocks commit into one of MGX_RES_SLOTS replicas of the record (by block index) so that thousands of
+// blocks do not queue on one address; a one-block kernel folds the replicas into record 0 before read-back.
+#define MGX_RES_SLOTS 128

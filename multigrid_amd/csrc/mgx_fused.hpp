@@ -125,7 +125,7 @@ __device__ inline void mgx_exact_add_nb(u64 &lo, u64 &hi, double a, unsigned &ov
   hi += ahi + (lo < alo ? 1ull : 0ull);
 }
 
-template <typename T, int TY, bool BOXES, int NW>
+template <typename T, int TY, int BOXES, int NW>
 __device__ inline void mgx_fused_body(const T *__restrict__ src, T *__restrict__ dst, const MgxGeom &g,
                                       const MgxSweepParams<T> &p, const MgxBox *__restrict__ bx, const int nb,
                                       const int tx0, const int ty0, const int zc0, const int zc1, const int reduce,
@@ -262,10 +262,28 @@ __device__ inline void mgx_fused_body(const T *__restrict__ src, T *__restrict__
   make_zsets(zc0 - 1 + g.z0, (zc0 - 1) & 1);
   MGX_SYNC();
 
-  T err = (T)0;
+  T err = (T)0;                    // max |vv - V|, squared once at the end (rounding is monotone: same bits)
   u64 slo = 0, shi = 0;
+  double fh = 0.0, fl2 = 0.0;      // exact partial sums of this lane, moved into (slo, shi) every NSET planes
   unsigned ovf = 0;
   unsigned zmm = 0u;               // Z set of plane k-2
+  static_assert(2 * R * NSET <= MGX_FAST_SUM_CELLS, "partial sums must stay exact between two flushes");
+  // |V| of R cells into the sum: two-double partial sums while every value is below the fast limit (the
+  // branch is uniform and practically never taken), the integer path otherwise
+#define MGX_SUM_R(val, cond)                                                           \
+  {                                                                                    \
+    double a_[R];                                                                      \
+    bool big_ = false;                                                                 \
+    _Pragma("unroll") for (int j = 0; j < R; ++j) {                                    \
+      a_[j] = (cond) ? fabs((double)(val)) : 0.0;                                      \
+      big_ = big_ || !(a_[j] < MGX_FAST_SUM_LIMIT);                                    \
+    }                                                                                  \
+    if (__builtin_expect(__any(big_), 0)) {                                            \
+      _Pragma("unroll") for (int j = 0; j < R; ++j) mgx_exact_add_nb(slo, shi, a_[j], ovf); \
+    } else {                                                                           \
+      _Pragma("unroll") for (int j = 0; j < R; ++j) mgx_fast_sum_add(fh, fl2, a_[j]);  \
+    }                                                                                  \
+  }
 
   for (int kb = zc0 - 1; kb <= zc1 + 1; kb += NSET) {
 #pragma unroll
@@ -304,7 +322,11 @@ __device__ inline void mgx_fused_body(const T *__restrict__ src, T *__restrict__
           actv[j] = (fl[j] & (q ? MGX_F_BLK1 : MGX_F_BLK0)) != 0;
           const T vc = cB[j], partner = cR[j];
           T vv;
-          if (BOXES) {
+          if (BOXES == 1) {       // only boxes with rho = 1 reach this tile: "is the cell constant" is all that matters
+            const unsigned sc = (q ? mx[j][2] : mx[j][1]) & my[j][1] & z0s;
+            const T avg = (sc & cmask) ? vc : mgx_avg_uniform<T>(partner, other[j], vym[j], vyp[j], mR[j], nR[j], p.w);
+            vv = p.s1 * vc + p.s2 * avg;
+          } else if (BOXES == 2) {
             const unsigned X0 = q ? mx[j][2] : mx[j][1], Xm = q ? mx[j][1] : mx[j][0], Xp = q ? mx[j][3] : mx[j][2];
             const unsigned XY = X0 & my[j][1];
             vv = mgx_cell_new_sets<T>(vc, q ? partner : other[j], q ? other[j] : partner, vym[j], vyp[j], mR[j], nR[j],
@@ -328,11 +350,12 @@ __device__ inline void mgx_fused_body(const T *__restrict__ src, T *__restrict__
           for (int j = 0; j < R; ++j) {
             const int q = (iy[j] + zg) & 1;
             const bool own = actv[j] && zown && (fl[j] & (q ? MGX_F_OWN1 : MGX_F_OWN0)) != 0;
+            actv[j] = own;
             const T d = cB[j] - vold[j];
-            const T d2 = own ? d * d : (T)0;
-            err = d2 > err ? d2 : err;
-            if (reduce & 2) mgx_exact_add_nb(slo, shi, own ? (double)(cB[j] < (T)0 ? -cB[j] : cB[j]) : 0.0, ovf);
+            const T ad = own ? (d < (T)0 ? -d : d) : (T)0;
+            err = ad > err ? ad : err;
           }
+          if (reduce & 2) MGX_SUM_R(cB[j], actv[j])
         }
       }
       make_zsets(zg + 1, (k + 1) & 1);                      // for the next step; this step reads the other parity
@@ -357,7 +380,11 @@ __device__ inline void mgx_fused_body(const T *__restrict__ src, T *__restrict__
           actv[j] = (fl[j] & (q ? MGX_F_RED1 : MGX_F_RED0)) != 0;
           const T vc = mR[j], partner = mB[j];
           T vv;
-          if (BOXES) {
+          if (BOXES == 1) {
+            const unsigned sc = (q ? mx[j][2] : mx[j][1]) & my[j][1] & zm;
+            const T avg = (sc & cmask) ? vc : mgx_avg_uniform<T>(partner, other[j], vym[j], vyp[j], below[j], cB[j], p.w);
+            vv = p.s1 * vc + p.s2 * avg;
+          } else if (BOXES == 2) {
             const unsigned X0 = q ? mx[j][2] : mx[j][1], Xm = q ? mx[j][1] : mx[j][0], Xp = q ? mx[j][3] : mx[j][2];
             const unsigned XY = X0 & my[j][1];
             vv = mgx_cell_new_sets<T>(vc, q ? partner : other[j], q ? other[j] : partner, vym[j], vyp[j], below[j], cB[j],
@@ -381,10 +408,10 @@ __device__ inline void mgx_fused_body(const T *__restrict__ src, T *__restrict__
 #pragma unroll
           for (int j = 0; j < R; ++j) {
             const T d = mR[j] - vold[j];
-            const T d2 = actv[j] ? d * d : (T)0;
-            err = d2 > err ? d2 : err;
-            if (reduce & 2) mgx_exact_add_nb(slo, shi, actv[j] ? (double)(mR[j] < (T)0 ? -mR[j] : mR[j]) : 0.0, ovf);
+            const T ad = actv[j] ? (d < (T)0 ? -d : d) : (T)0;
+            err = ad > err ? ad : err;
           }
+          if (reduce & 2) MGX_SUM_R(mR[j], actv[j])
         }
       }
 
@@ -396,17 +423,20 @@ __device__ inline void mgx_fused_body(const T *__restrict__ src, T *__restrict__
       zmm = zm;                                             // Z set of plane k-1 = (k+1)-2 for the next red phase
       MGX_SYNC();
     }
+    if (reduce & 2) mgx_fast_sum_flush(fh, fl2, slo, shi);
   }
+#undef MGX_SUM_R
 #undef MGX_FETCH
 #undef MGX_COLOUR
 #undef MGX_STAGE
 
-  if (reduce) mgx_block_commit<NW + 1>((double)err, slo, shi, ovf, reduce, res);
+  if (reduce) mgx_block_commit<NW + 1>((double)(err * err), slo, shi, ovf, reduce, res);
 }
 
 // One launch per tile class: `tiles` lists the tiles (x fastest, then y, then z chunk) that boxes do not
-// reach (BOXES = false) or do reach (BOXES = true); the host builds both lists from the box table.
-template <typename T, int TY, bool BOXES, int NW>
+// reach (BOXES = 0), that only boxes with rho = 1 reach (1), or that some box with rho != 1 reaches (2); the host
+// builds the three lists from the box table.
+template <typename T, int TY, int BOXES, int NW>
 __global__ __launch_bounds__((NW + 1) * 64) void k_fused_sweep(const T *__restrict__ src, T *__restrict__ dst, const MgxGeom g,
                                                      const MgxSweepParams<T> p, const MgxBox *__restrict__ bx,
                                                      const int nb, const int ZC, const int ntx, const int nty,
@@ -435,8 +465,8 @@ __global__ __launch_bounds__((NW + 1) * 64) void k_fused_sweep(const T *__restri
 
 struct MgxFusedPlan {            // per level: tile decomposition and the two tile lists (device)
   int ty = 0, nw = 4, ZC = 0, ntx = 0, nty = 0, nzc = 0;
-  int n_fast = 0, n_box = 0;
-  int *d_tiles = nullptr;        // n_fast entries, then n_box entries
+  int n_fast = 0, n_const = 0, n_box = 0;
+  int *d_tiles = nullptr;        // n_fast entries, then n_const, then n_box entries
   bool valid = false;
 };
 
@@ -468,7 +498,7 @@ static int mgx_fused_make_plan(MgxFusedPlan &pl, const MgxGeom &g, const std::ve
   pl.nzc = (g.n3 + ZC - 1) / ZC;
   const long long ntile = per_chunk * pl.nzc;
   if (ntile > 0x7fffffffLL) return -1;
-  std::vector<int> fast, boxed;
+  std::vector<int> fast, consto, boxed;   // no box in reach / only rho = 1 boxes / some box with rho != 1
   for (int tz = 0; tz < pl.nzc; ++tz)
     for (int ty = 0; ty < pl.nty; ++ty)
       for (int tx = 0; tx < pl.ntx; ++tx) {
@@ -476,13 +506,18 @@ static int mgx_fused_make_plan(MgxFusedPlan &pl, const MgxGeom &g, const std::ve
         const int y0 = 1 + ty * pl.ty - 2, y1 = 1 + (ty + 1) * pl.ty + 1;
         const int zc0 = 1 + tz * ZC, zc1 = std::min(zc0 + ZC - 1, g.n3);
         const int z0 = zc0 - 2 + g.z0, z1 = zc1 + 2 + g.z0;
-        bool hit = false;
-        for (const MgxBox &b : boxes)
-          hit |= b.lo[0] <= x1 && x0 <= b.hi[0] && b.lo[1] <= y1 && y0 <= b.hi[1] && b.lo[2] <= z1 && z0 <= b.hi[2];
-        (hit ? boxed : fast).push_back((tz * pl.nty + ty) * pl.ntx + tx);
+        bool hit = false, hit_rho = false;
+        for (const MgxBox &b : boxes) {
+          const bool h = b.lo[0] <= x1 && x0 <= b.hi[0] && b.lo[1] <= y1 && y0 <= b.hi[1] && b.lo[2] <= z1 && z0 <= b.hi[2];
+          hit |= h;
+          hit_rho |= h && !b.rho_is_one;
+        }
+        (hit_rho ? boxed : hit ? consto : fast).push_back((tz * pl.nty + ty) * pl.ntx + tx);
       }
   pl.n_fast = (int)fast.size();
+  pl.n_const = (int)consto.size();
   pl.n_box = (int)boxed.size();
+  fast.insert(fast.end(), consto.begin(), consto.end());
   fast.insert(fast.end(), boxed.begin(), boxed.end());
   if (hipMalloc((void **)&pl.d_tiles, sizeof(int) * fast.size()) != hipSuccess) return -1;
   if (hipMemcpyAsync(pl.d_tiles, fast.data(), sizeof(int) * fast.size(), hipMemcpyHostToDevice, st) != hipSuccess) return -1;
@@ -498,23 +533,28 @@ static int mgx_fused_launch_cfg(const MgxFusedPlan &pl, const T *src, T *dst, co
   constexpr int TXP = 64;
   constexpr size_t lds = (size_t)3 * 2 * (TXP + 2) * (TY + 6) * sizeof(T) + sizeof(MgxBoxLds<T>);
   if (lds > 64 * 1024) {      // beyond the default dynamic LDS limit: raise it for both kernels
-    if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_fused_sweep<T, TY, false, NW>),
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_fused_sweep<T, TY, 0, NW>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
-        hipFuncSetAttribute(reinterpret_cast<const void *>(k_fused_sweep<T, TY, true, NW>),
+        hipFuncSetAttribute(reinterpret_cast<const void *>(k_fused_sweep<T, TY, 1, NW>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
+        hipFuncSetAttribute(reinterpret_cast<const void *>(k_fused_sweep<T, TY, 2, NW>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
       return -1;
   }
   // The (few, slower) tiles that boxes reach run on the side stream, concurrently with the others.
-  const bool side = pl.n_box > 0 && pl.n_fast > 0 && aux != nullptr;
+  const bool side = pl.n_box > 0 && pl.n_fast + pl.n_const > 0 && aux != nullptr;
   hipStream_t sb = side ? aux : st;
   if (side) {
     if (hipEventRecord(ev_fork, st) != hipSuccess || hipStreamWaitEvent(aux, ev_fork, 0) != hipSuccess) return -1;
   }
   if (pl.n_box > 0)
-    hipLaunchKernelGGL((k_fused_sweep<T, TY, true, NW>), dim3((unsigned)pl.n_box), dim3((NW + 1) * 64), lds, sb, src, dst, g, p, bx, nb,
+    hipLaunchKernelGGL((k_fused_sweep<T, TY, 2, NW>), dim3((unsigned)pl.n_box), dim3((NW + 1) * 64), lds, sb, src, dst, g, p, bx, nb,
+                       pl.ZC, pl.ntx, pl.nty, pl.d_tiles + pl.n_fast + pl.n_const, reduce, res);
+  if (pl.n_const > 0)
+    hipLaunchKernelGGL((k_fused_sweep<T, TY, 1, NW>), dim3((unsigned)pl.n_const), dim3((NW + 1) * 64), lds, st, src, dst, g, p, bx, nb,
                        pl.ZC, pl.ntx, pl.nty, pl.d_tiles + pl.n_fast, reduce, res);
   if (pl.n_fast > 0)
-    hipLaunchKernelGGL((k_fused_sweep<T, TY, false, NW>), dim3((unsigned)pl.n_fast), dim3((NW + 1) * 64), lds, st, src, dst, g, p, bx, nb,
+    hipLaunchKernelGGL((k_fused_sweep<T, TY, 0, NW>), dim3((unsigned)pl.n_fast), dim3((NW + 1) * 64), lds, st, src, dst, g, p, bx, nb,
                        pl.ZC, pl.ntx, pl.nty, pl.d_tiles, reduce, res);
   if (side) {
     if (hipEventRecord(ev_join, aux) != hipSuccess || hipStreamWaitEvent(st, ev_join, 0) != hipSuccess) return -1;

@@ -42,6 +42,7 @@ __device__ inline void mgx_block_commit(double err, u64 lo, u64 hi, unsigned ovf
   }
   __syncthreads();
   if (threadIdx.x == 0) {
+    res += MGX_RES_WORDS * (1 + (blockIdx.x + blockIdx.y * 7 + blockIdx.z * 13) % MGX_RES_SLOTS);
     if (reduce & 1) {
       u64 m = sh[0][0];
 #pragma unroll
@@ -59,6 +60,30 @@ __device__ inline void mgx_block_commit(double err, u64 lo, u64 hi, unsigned ovf
         if (d[k]) atomicAdd(&res[1 + k], d[k]);
       if (d[4]) atomicAdd(&res[5], d[4]);
     }
+  }
+}
+
+// fold the replicas into record 0 (max of word 0, sums of words 1..5); one block of MGX_RES_SLOTS threads
+__global__ __launch_bounds__(MGX_RES_SLOTS) void k_fold_result(u64 *__restrict__ res) {
+  __shared__ u64 sh[MGX_RES_SLOTS / 64][6];
+  const u64 *mine = res + MGX_RES_WORDS * (1 + threadIdx.x);
+  u64 m = mine[0];
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { const u64 t = __shfl_xor(m, o, 64); m = t > m ? t : m; }
+  u64 d[5];
+#pragma unroll
+  for (int k = 0; k < 5; ++k) d[k] = mgx_wave_add(mine[1 + k]);
+  const int w = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) { sh[w][0] = m; for (int k = 0; k < 5; ++k) sh[w][1 + k] = d[k]; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    u64 mm = sh[0][0], dd[5] = {sh[0][1], sh[0][2], sh[0][3], sh[0][4], sh[0][5]};
+    for (int i = 1; i < MGX_RES_SLOTS / 64; ++i) {
+      mm = sh[i][0] > mm ? sh[i][0] : mm;
+      for (int k = 0; k < 5; ++k) dd[k] += sh[i][1 + k];
+    }
+    res[0] = mm;
+    for (int k = 0; k < 5; ++k) res[1 + k] = dd[k];
   }
 }
 

@@ -52,9 +52,9 @@ int64_t orc_count_nonconst(const orc_level *L)
   return n;
 }
 
-/* Exact |V| accumulation: acc += floor(absval * 2^72) as a 128-bit integer
- * (limbs[0] low, limbs[1] high).  Values >= 2^20 or non-finite cannot be
- * accumulated safely for 2^34 cells and raise *overflow. */
+/* Exact |V| accumulation: acc += rne(absval * 2^72) (round to nearest, ties to
+ * even) as a 128-bit integer (limbs[0] low, limbs[1] high).  Values >= 2^20 or
+ * non-finite cannot be accumulated safely for 2^34 cells and raise *overflow. */
 #define ORC_Q 72
 void orc_exact_add(uint64_t limbs[2], double absval, int *overflow)
 {
@@ -68,8 +68,12 @@ void orc_exact_add(uint64_t limbs[2], double absval, int *overflow)
   int sh = e - 1075 + ORC_Q;                 /* value = m * 2^(e-1075) */
   unsigned __int128 add;
   if (sh >= 0) add = (unsigned __int128)m << sh;
-  else if (sh > -64) add = (unsigned __int128)(m >> (-sh));
-  else add = 0;
+  else if (sh > -64) {
+    const int r = -sh;
+    uint64_t q = m >> r, rem = m & ((1ull << r) - 1), half = 1ull << (r - 1);
+    if (rem > half || (rem == half && (q & 1))) q += 1;
+    add = q;
+  } else add = 0;                            /* m < 2^53 <= half of 2^64: rounds to 0 */
   unsigned __int128 acc = ((unsigned __int128)limbs[1] << 64) | limbs[0];
   acc += add;
   limbs[0] = (uint64_t)acc;

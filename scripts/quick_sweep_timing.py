@@ -1,4 +1,5 @@
 """ad-hoc: time red-black sweeps of one level on the GPU (not the official bench)"""
+import os
 import sys
 import time
 
@@ -29,7 +30,11 @@ lv.result()
 for reps in (10, 30):
     ctx.sync()
     t0 = time.perf_counter()
-    lv.sweep(reps, red)
+    if os.environ.get("PER_SWEEP"):
+        for _ in range(reps):
+            lv.sweep(1, red)
+    else:
+        lv.sweep(reps, red)
     ctx.sync()
     t1 = time.perf_counter()
     ms = (t1 - t0) / reps * 1e3
