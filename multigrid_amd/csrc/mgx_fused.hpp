@@ -125,36 +125,51 @@ __device__ inline void mgx_exact_add_nb(u64 &lo, u64 &hi, double a, unsigned &ov
   hi += ahi + (lo < alo ? 1ull : 0ull);
 }
 
-template <typename T, int TY, int BOXES, int NW>
-__device__ inline void mgx_fused_body(const T *__restrict__ src, T *__restrict__ dst, const MgxGeom &g,
-                                      const MgxSweepParams<T> &p, const MgxBox *__restrict__ bx, const int nb,
-                                      const int tx0, const int ty0, const int zc0, const int zc1, const int reduce,
-                                      u64 *__restrict__ res, T *__restrict__ lds, MgxBoxLds<T> *__restrict__ bl) {
+// P0 and HALO specialise the body per wave.  With x-pairs starting at an odd x, the odd ("black") cell of a
+// pair is its second cell iff y + z is odd.  Row waves own rows w, w + NW, ... (NW even), so y + z has ONE
+// parity for all items of a wave on a given plane, and it alternates from plane to plane; the plane loop is
+// unrolled an even number of times, so every "which cell of the pair" question has a compile-time answer
+// given P0 = parity of y + z of item 0 on the first plane: colour conversion becomes register naming and
+// the neighbour side, the flag tested and the packing of the stored pair become constants.  The halo wave
+// (HALO) takes the even staged rows as item 0 and the odd ones as item 1, so item j adds j to the parity.
+template <typename T, int TY, int BOXES, int NW, int P0, bool HALO>
+__device__ __forceinline__ void mgx_fused_body(const T *__restrict__ src, T *__restrict__ dst, const MgxGeom &g,
+                                               const MgxSweepParams<T> &p, const MgxBox *__restrict__ bx, const int nb,
+                                               const int tx0, const int ty0, const int zc0, const int zc1,
+                                               const int reduce, u64 *__restrict__ res, T *__restrict__ lds,
+                                               MgxBoxLds<T> *__restrict__ bl) {
   typedef typename MgxVec2<T>::type V2;
   constexpr int TXP = 64;
   constexpr int LP = TXP + 2;            // pairs per staged row
   constexpr int LR = TY + 4;             // staged rows
   constexpr int PL = LP * (LR + 2);      // pairs per staged plane incl. one guard row above and below
-  constexpr int R = LR / NW;             // rows per row-wave
-  constexpr int D = 1;                   // planes fetched ahead of their first use
+  constexpr int RW = LR / NW;            // rows per row-wave
+  constexpr int R = HALO ? 2 : RW;       // items of a lane
+#ifndef MGX_FUSED_D
+#define MGX_FUSED_D 1
+#endif
+  constexpr int D = MGX_FUSED_D;         // planes fetched ahead of their first use (odd, so that NSET is even)
   constexpr int NSET = 3 + D;            // register plane sets
   static_assert(LR % NW == 0, "staged rows must divide over the row waves");
-  static_assert(2 * LR <= 64, "halo pairs must fit one wave");
+  static_assert(LR <= 64 && LR % 2 == 0, "halo pairs of one row parity must fit one wave");
+  static_assert(NW % 2 == 0 && NSET % 2 == 0, "the parity of y + z must be a compile-time function of the unroll position");
+#define MGX_Q(u, j) (((P0) + (u) + (HALO ? (j) : 0)) & 1)     /* position of the odd cell in pair j, unroll position u */
   auto L = [&](int slot, int comp, int li) -> T & { return lds[(slot * 2 + comp) * PL + li]; };
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 
   // ---- items of this lane.  Everything below is branch-free per item: items (or cells) that must not be
-  // touched compute anyway and are masked by value selects; their loads, LDS writes and stores are
-  // redirected to harmless addresses (element 0 of the buffers' leading pad, LDS guard row). ----
-  int li[R], fl[R], iy[R];
-  long long go[R], gst[R];
+  // touched compute anyway and are masked by value selects; their loads and LDS writes are redirected to
+  // harmless addresses (first element of the plane, LDS guard row); only the stores are predicated. ----
+  int li[R], fl[R];
+  unsigned gob[R];                       // byte offset of the pair inside a plane
+  bool st[R];
   unsigned mx[R][4], my[R][3];           // BOXES: boxes whose x range holds xs-1..xs+2 / y range holds y-1..y+1
 #pragma unroll
   for (int j = 0; j < R; ++j) {
     int r, pc;
     bool valid;
-    if (wave < NW) { r = wave + NW * j; pc = lane + 1; valid = true; }
-    else { r = lane >> 1; pc = (lane & 1) ? LP - 1 : 0; valid = (j == 0) && lane < 2 * LR; }
+    if (!HALO) { r = wave + NW * j; pc = lane + 1; valid = true; }
+    else { r = 2 * (lane >> 1) + j; pc = (lane & 1) ? LP - 1 : 0; valid = lane < LR; }
     const int y = ty0 - 2 + r, xs = tx0 - 2 + 2 * pc;
     const bool halo = (pc == 0 || pc == LP - 1);
     int f = 0;
@@ -174,9 +189,8 @@ __device__ inline void mgx_fused_body(const T *__restrict__ src, T *__restrict__
     const bool ld = (f & MGX_F_LOAD) != 0;
     li[j] = ld ? (r + 1) * LP + pc : 0;
     fl[j] = f;
-    iy[j] = y;
-    go[j] = ld ? g.front + (long long)(xs - 1) + (long long)g.px * y : g.front;
-    gst[j] = (f & MGX_F_STORE) ? go[j] : -1;
+    gob[j] = (unsigned)((ld ? g.front + (long long)(xs - 1) + (long long)g.px * y : g.front) * (long long)sizeof(T));
+    st[j] = (f & MGX_F_STORE) != 0;
     if (BOXES) {
 #pragma unroll
       for (int d = 0; d < 4; ++d) mx[j][d] = 0u;
@@ -192,14 +206,14 @@ __device__ inline void mgx_fused_body(const T *__restrict__ src, T *__restrict__
     }
   }
   unsigned cmask = 0u, rmask = 0u;
-  int blo2 = 1, bhi2 = 0;                // z range of "my" box (wave 4: lane = box)
+  int blo2 = 1, bhi2 = 0;                // z range of "my" box (halo wave: lane = box)
   if (BOXES) {
     for (int b = 0; b < nb; ++b) {
       cmask |= bx[b].constant ? (1u << b) : 0u;
       rmask |= bx[b].rho_is_one ? 0u : (1u << b);
     }
-    if (wave == NW && lane < nb) { blo2 = bx[lane].lo[2]; bhi2 = bx[lane].hi[2]; }
-    if (threadIdx.x <= MGX_MAX_FUSED_BOXES) {
+    if (HALO && lane < nb) { blo2 = bx[lane].lo[2]; bhi2 = bx[lane].hi[2]; }
+    if (!HALO && threadIdx.x <= MGX_MAX_FUSED_BOXES) {
       const T rb = threadIdx.x < nb ? (T)bx[threadIdx.x].rho : (T)1;
       bl->rho[threadIdx.x] = rb;
       T r[6] = {rb * p.a[0], rb * p.a[0], rb * p.a[1], rb * p.a[1], rb * p.a[2], rb * p.a[2]};
@@ -210,9 +224,9 @@ __device__ inline void mgx_fused_body(const T *__restrict__ src, T *__restrict__
       bl->win[threadIdx.x][2] = r[4] / s;
     }
   }
-  // Z sets for planes zz-1, zz, zz+1 (global), written by wave 4 into parity slot `par`
+  // Z sets for planes zz-1, zz, zz+1 (global), written by the halo wave into parity slot `par`
   auto make_zsets = [&](int zz, int par) {
-    if (BOXES && wave == NW) {
+    if (BOXES && HALO) {
 #pragma unroll
       for (int d = 0; d < 3; ++d) {
         const unsigned long long m = __ballot(blo2 <= zz - 1 + d && zz - 1 + d <= bhi2);
@@ -226,39 +240,35 @@ __device__ inline void mgx_fused_body(const T *__restrict__ src, T *__restrict__
   // that a set changes role by renaming, never by a copy: a copy would make the wave wait for the newest
   // load).  At step k (position u in the unrolled group) W[u] = plane k-1, W[u+1] = plane k,
   // W[u+2] = plane k+1, ..., W[u+NSET-1] = plane k+1+D, fetched now and first needed D steps later.
-  // A set holds a pair by COLOUR, not by position: WB = the odd ("black") cell, WR = the even ("red")
-  // cell.  Which of the two sits first in memory alternates with y + z; that only matters when a pair
-  // is fetched or stored and for the side of the x neighbour in the adjacent pair, so the arithmetic
-  // below is free of position selects.  LDS likewise: array 0 of a slot = black values, array 1 = red.
-  T WB[NSET][R], WR[NSET][R], below[R];
-#define MGX_FETCH(z, a0, a1) /* raw: first / second cell of the pair; nothing may touch them yet */ \
+  // A set keeps the pair as loaded (first cell, second cell), in the very registers the 16-byte load
+  // wrote; which of the two is the odd ("black") cell is the compile-time MGX_Q of the plane's unroll
+  // position.  Every fetch is unconditional (a plane index past the march is clamped and the data
+  // ignored): a load under a condition would need a merge copy right behind it.  LDS is split by
+  // colour: array 0 of a slot = black values, array 1 = red.
+  V2 W[NSET][R];
+  T below[R];
+#define MGX_BLK(set, up, j) (MGX_Q(up, j) ? W[set][j].y : W[set][j].x)      /* odd cell of pair j (value) */
+#define MGX_RED(set, up, j) (MGX_Q(up, j) ? W[set][j].x : W[set][j].y)      /* even cell */
+#define MGX_SET_BLK(set, up, j, v) { if (MGX_Q(up, j)) W[set][j].y = (v); else W[set][j].x = (v); }
+#define MGX_SET_RED(set, up, j, v) { if (MGX_Q(up, j)) W[set][j].x = (v); else W[set][j].y = (v); }
+#define MGX_FETCH(z, set)                                                              \
   {                                                                                    \
-    const long long pb_ = pzl * ((z) + 1);                                             \
+    const char *pb_ = reinterpret_cast<const char *>(src + pzl * ((z) + 1));           \
+    _Pragma("unroll") for (int j = 0; j < R; ++j) W[set][j] = *reinterpret_cast<const V2 *>(pb_ + gob[j]); \
+  }
+#define MGX_STAGE(slot, set, up)                                                       \
+  {                                                                                    \
     _Pragma("unroll") for (int j = 0; j < R; ++j) {                                    \
-      const V2 t_ = *reinterpret_cast<const V2 *>(src + pb_ + go[j]);                  \
-      a0[j] = t_.x; a1[j] = t_.y;                                                      \
+      L(slot, 0, li[j]) = MGX_BLK(set, up, j);                                         \
+      L(slot, 1, li[j]) = MGX_RED(set, up, j);                                         \
     }                                                                                  \
   }
-#define MGX_COLOUR(z, aB, aR) /* in place: (first, second) -> (odd cell, even cell) of plane z */ \
-  {                                                                                    \
-    _Pragma("unroll") for (int j = 0; j < R; ++j) {                                    \
-      const bool q_ = ((iy[j] + (z) + g.z0) & 1) != 0;   /* odd cell is the second one */ \
-      const T b_ = q_ ? aR[j] : aB[j], r_ = q_ ? aB[j] : aR[j];                        \
-      aB[j] = b_; aR[j] = r_;                                                          \
-    }                                                                                  \
-  }
-#define MGX_STAGE(slot, aB, aR)                                                        \
-  {                                                                                    \
-    _Pragma("unroll") for (int j = 0; j < R; ++j) { L(slot, 0, li[j]) = aB[j]; L(slot, 1, li[j]) = aR[j]; } \
-  }
 #pragma unroll
-  for (int j = 0; j < R; ++j) { WB[NSET - 1][j] = WR[NSET - 1][j] = below[j] = (T)0; }
+  for (int j = 0; j < R; ++j) { W[NSET - 1][j].x = W[NSET - 1][j].y = below[j] = (T)0; }
 #pragma unroll
-  for (int sI = 0; sI < NSET - 1; ++sI) MGX_FETCH(zc0 - 2 + sI, WB[sI], WR[sI])
-#pragma unroll
-  for (int sI = 0; sI < 2; ++sI) MGX_COLOUR(zc0 - 2 + sI, WB[sI], WR[sI])      // planes k-1 and k of the first step
+  for (int sI = 0; sI < NSET - 1; ++sI) MGX_FETCH(min(zc0 - 2 + sI, zc1 + 2), sI)
   int sk = 0;                      // LDS slot of plane k; k-1 lives in sk-1, k+1 in sk+1 (mod 3)
-  MGX_STAGE(sk, WB[1], WR[1])
+  MGX_STAGE(sk, 1, 0)              // set 1 = plane zc0-1 = plane k of the first step (unroll position 0)
   make_zsets(zc0 - 1 + g.z0, (zc0 - 1) & 1);
   MGX_SYNC();
 
@@ -267,7 +277,7 @@ __device__ inline void mgx_fused_body(const T *__restrict__ src, T *__restrict__
   double fh = 0.0, fl2 = 0.0;      // exact partial sums of this lane, moved into (slo, shi) every NSET planes
   unsigned ovf = 0;
   unsigned zmm = 0u;               // Z set of plane k-2
-  static_assert(2 * R * NSET <= MGX_FAST_SUM_CELLS, "partial sums must stay exact between two flushes");
+  static_assert(2 * RW * NSET <= MGX_FAST_SUM_CELLS, "partial sums must stay exact between two flushes");
   // |V| of R cells into the sum: two-double partial sums while every value is below the fast limit (the
   // branch is uniform and practically never taken), the integer path otherwise
 #define MGX_SUM_R(val, cond)                                                           \
@@ -290,15 +300,10 @@ __device__ inline void mgx_fused_body(const T *__restrict__ src, T *__restrict__
     for (int u = 0; u < NSET; ++u) {
       const int k = kb + u;
       if (k > zc1 + 1) break;
-      T(&mB)[R] = WB[u % NSET], (&mR)[R] = WR[u % NSET];
-      T(&cB)[R] = WB[(u + 1) % NSET], (&cR)[R] = WR[(u + 1) % NSET];
-      T(&nR)[R] = WR[(u + 2) % NSET];
-      T(&nB)[R] = WB[(u + 2) % NSET];
-      T(&fB)[R] = WB[(u + NSET - 1) % NSET], (&fR)[R] = WR[(u + NSET - 1) % NSET];
+      const int SM = u % NSET, SC = (u + 1) % NSET, SN = (u + 2) % NSET, SF = (u + NSET - 1) % NSET;   // sets of planes k-1, k, k+1, k+1+D
       const int zg = k + g.z0;
       const int sm = sk == 0 ? 2 : sk - 1, sp = sk == 2 ? 0 : sk + 1;
-      if (k + 1 + D <= zc1 + 2) MGX_FETCH(k + 1 + D, fB, fR)
-      MGX_COLOUR(k + 1, nB, nR)                             // plane k+1 was fetched D steps ago: first touch now
+      MGX_FETCH(min(k + 1 + D, zc1 + 2), SF)
       unsigned zm = 0u, z0s = 0u, zp = 0u;
       if (BOXES) { zm = bl->zsets[k & 1][0]; z0s = bl->zsets[k & 1][1]; zp = bl->zsets[k & 1][2]; }
 
@@ -307,128 +312,130 @@ __device__ inline void mgx_fused_body(const T *__restrict__ src, T *__restrict__
       // the items of a lane overlap; cells that must not change are masked by value selects)
       if (zg >= 1 && zg <= g.n3g) {
         const bool zown = k >= zc0 && k <= zc1;
-        T other[R], vym[R], vyp[R], vold[R];
+        T other[R], vym[R], vyp[R], vold[R], cnew[R];
         bool actv[R];
 #pragma unroll
         for (int j = 0; j < R; ++j) {
-          const int q = (iy[j] + zg) & 1;                   // position of the odd cell in the pair
-          other[j] = L(sk, 1, li[j] + (2 * q - 1));
+          other[j] = L(sk, 1, li[j] + (2 * MGX_Q(u, j) - 1));
           vym[j] = L(sk, 1, li[j] - LP);
           vyp[j] = L(sk, 1, li[j] + LP);
         }
 #pragma unroll
         for (int j = 0; j < R; ++j) {
-          const int q = (iy[j] + zg) & 1;
+          const int q = MGX_Q(u, j);
           actv[j] = (fl[j] & (q ? MGX_F_BLK1 : MGX_F_BLK0)) != 0;
-          const T vc = cB[j], partner = cR[j];
+          const T vc = MGX_BLK(SC, u, j), partner = MGX_RED(SC, u, j);
+          const T zlo = MGX_RED(SM, u + 1, j), zhi = MGX_RED(SN, u + 1, j);   // planes k-1 and k+1 (same parity as each other)
           T vv;
           if (BOXES == 1) {       // only boxes with rho = 1 reach this tile: "is the cell constant" is all that matters
             const unsigned sc = (q ? mx[j][2] : mx[j][1]) & my[j][1] & z0s;
-            const T avg = (sc & cmask) ? vc : mgx_avg_uniform<T>(partner, other[j], vym[j], vyp[j], mR[j], nR[j], p.w);
+            const T avg = (sc & cmask) ? vc : mgx_avg_uniform<T>(partner, other[j], vym[j], vyp[j], zlo, zhi, p.w);
             vv = p.s1 * vc + p.s2 * avg;
           } else if (BOXES == 2) {
             const unsigned X0 = q ? mx[j][2] : mx[j][1], Xm = q ? mx[j][1] : mx[j][0], Xp = q ? mx[j][3] : mx[j][2];
             const unsigned XY = X0 & my[j][1];
-            vv = mgx_cell_new_sets<T>(vc, q ? partner : other[j], q ? other[j] : partner, vym[j], vyp[j], mR[j], nR[j],
+            vv = mgx_cell_new_sets<T>(vc, q ? partner : other[j], q ? other[j] : partner, vym[j], vyp[j], zlo, zhi,
                                       XY & z0s, Xm & my[j][1] & z0s, Xp & my[j][1] & z0s, X0 & my[j][0] & z0s,
                                       X0 & my[j][2] & z0s, XY & zm, XY & zp, cmask, rmask, bl, p);
           } else {
             // x-1 and x+1 carry the same weight and a*w + b*w commutes exactly: no need to order them
 #ifdef MGX_ABLATE_COMPUTE
-            vv = vc + other[j] + vym[j] + vyp[j] + mR[j] + nR[j] + partner;
+            vv = vc + other[j] + vym[j] + vyp[j] + zlo + zhi + partner;
 #else
-            vv = p.s1 * vc + p.s2 * mgx_avg_uniform<T>(partner, other[j], vym[j], vyp[j], mR[j], nR[j], p.w);
+            vv = p.s1 * vc + p.s2 * mgx_avg_uniform<T>(partner, other[j], vym[j], vyp[j], zlo, zhi, p.w);
 #endif
           }
           vold[j] = vc;
-          cB[j] = actv[j] ? vv : vc;
+          cnew[j] = actv[j] ? vv : vc;
+          MGX_SET_BLK(SC, u, j, cnew[j])
         }
 #pragma unroll
-        for (int j = 0; j < R; ++j) L(sk, 0, li[j]) = cB[j];
-        if (reduce) {
+        for (int j = 0; j < R; ++j) L(sk, 0, li[j]) = cnew[j];
+        if (!HALO && reduce) {    // halo pairs belong to the neighbouring tiles' reductions
 #pragma unroll
           for (int j = 0; j < R; ++j) {
-            const int q = (iy[j] + zg) & 1;
-            const bool own = actv[j] && zown && (fl[j] & (q ? MGX_F_OWN1 : MGX_F_OWN0)) != 0;
+            const bool own = actv[j] && zown && (fl[j] & (MGX_Q(u, j) ? MGX_F_OWN1 : MGX_F_OWN0)) != 0;
             actv[j] = own;
-            const T d = cB[j] - vold[j];
+            const T d = cnew[j] - vold[j];
             const T ad = own ? (d < (T)0 ? -d : d) : (T)0;
             err = ad > err ? ad : err;
           }
-          if (reduce & 2) MGX_SUM_R(cB[j], actv[j])
+          if (reduce & 2) MGX_SUM_R(cnew[j], actv[j])
         }
       }
       make_zsets(zg + 1, (k + 1) & 1);                      // for the next step; this step reads the other parity
       MGX_SYNC();
 
       // ---------------- red cells of plane k-1; store the finished plane ----------------
-      if (k - 1 >= zc0 && wave < NW) {
-        const int kr = k - 1, zgr = kr + g.z0;
-        const long long pb = pzl * (kr + 1);
-        T other[R], vym[R], vyp[R], vold[R];
+      if (!HALO && k - 1 >= zc0) {
+        const int kr = k - 1;
+        char *pb = reinterpret_cast<char *>(dst + pzl * (kr + 1));
+        T other[R], vym[R], vyp[R], vold[R], rnew[R];
         bool actv[R];
 #pragma unroll
         for (int j = 0; j < R; ++j) {
-          const int q = (1 + iy[j] + zgr) & 1;              // position of the even cell in the pair
-          other[j] = L(sm, 0, li[j] + (2 * q - 1));
+          other[j] = L(sm, 0, li[j] + (2 * MGX_Q(u, j) - 1));   // the even cell sits where the odd one sits a plane later
           vym[j] = L(sm, 0, li[j] - LP);
           vyp[j] = L(sm, 0, li[j] + LP);
         }
 #pragma unroll
         for (int j = 0; j < R; ++j) {
-          const int q = (1 + iy[j] + zgr) & 1;
+          const int q = MGX_Q(u, j);                        // position of the even cell in the pair on plane k-1
           actv[j] = (fl[j] & (q ? MGX_F_RED1 : MGX_F_RED0)) != 0;
-          const T vc = mR[j], partner = mB[j];
+          const T vc = MGX_RED(SM, u + 1, j), partner = MGX_BLK(SM, u + 1, j);
+          const T zhi = MGX_BLK(SC, u, j);                  // new black value of plane k
           T vv;
           if (BOXES == 1) {
             const unsigned sc = (q ? mx[j][2] : mx[j][1]) & my[j][1] & zm;
-            const T avg = (sc & cmask) ? vc : mgx_avg_uniform<T>(partner, other[j], vym[j], vyp[j], below[j], cB[j], p.w);
+            const T avg = (sc & cmask) ? vc : mgx_avg_uniform<T>(partner, other[j], vym[j], vyp[j], below[j], zhi, p.w);
             vv = p.s1 * vc + p.s2 * avg;
           } else if (BOXES == 2) {
             const unsigned X0 = q ? mx[j][2] : mx[j][1], Xm = q ? mx[j][1] : mx[j][0], Xp = q ? mx[j][3] : mx[j][2];
             const unsigned XY = X0 & my[j][1];
-            vv = mgx_cell_new_sets<T>(vc, q ? partner : other[j], q ? other[j] : partner, vym[j], vyp[j], below[j], cB[j],
+            vv = mgx_cell_new_sets<T>(vc, q ? partner : other[j], q ? other[j] : partner, vym[j], vyp[j], below[j], zhi,
                                       XY & zm, Xm & my[j][1] & zm, Xp & my[j][1] & zm, X0 & my[j][0] & zm,
                                       X0 & my[j][2] & zm, XY & zmm, XY & z0s, cmask, rmask, bl, p);
           } else {
 #ifdef MGX_ABLATE_COMPUTE
-            vv = vc + other[j] + vym[j] + vyp[j] + below[j] + cB[j] + partner;
+            vv = vc + other[j] + vym[j] + vyp[j] + below[j] + zhi + partner;
 #else
-            vv = p.s1 * vc + p.s2 * mgx_avg_uniform<T>(partner, other[j], vym[j], vyp[j], below[j], cB[j], p.w);
+            vv = p.s1 * vc + p.s2 * mgx_avg_uniform<T>(partner, other[j], vym[j], vyp[j], below[j], zhi, p.w);
 #endif
           }
           vold[j] = vc;
-          mR[j] = actv[j] ? vv : vc;
-          V2 out;
-          out.x = q ? partner : mR[j];
-          out.y = q ? mR[j] : partner;
-          *reinterpret_cast<V2 *>(dst + (gst[j] >= 0 ? pb + gst[j] : 0)) = out;
+          rnew[j] = actv[j] ? vv : vc;
+          MGX_SET_RED(SM, u + 1, j, rnew[j])
+          if (st[j]) *reinterpret_cast<V2 *>(pb + gob[j]) = W[SM][j];     // the finished pair, as it sits in memory
         }
         if (reduce) {
 #pragma unroll
           for (int j = 0; j < R; ++j) {
-            const T d = mR[j] - vold[j];
+            const T d = rnew[j] - vold[j];
             const T ad = actv[j] ? (d < (T)0 ? -d : d) : (T)0;
             err = ad > err ? ad : err;
           }
-          if (reduce & 2) MGX_SUM_R(mR[j], actv[j])
+          if (reduce & 2) MGX_SUM_R(rnew[j], actv[j])
         }
       }
 
       // ---------------- stage raw plane k+1; remember the black value under the next red plane ----------------
-      MGX_STAGE(sp, nB, nR)
+      MGX_STAGE(sp, SN, u + 1)
 #pragma unroll
-      for (int j = 0; j < R; ++j) below[j] = mB[j];
+      for (int j = 0; j < R; ++j) below[j] = MGX_BLK(SM, u + 1, j);
       sk = sp;
       zmm = zm;                                             // Z set of plane k-1 = (k+1)-2 for the next red phase
       MGX_SYNC();
     }
-    if (reduce & 2) mgx_fast_sum_flush(fh, fl2, slo, shi);
+    if (!HALO && (reduce & 2)) mgx_fast_sum_flush(fh, fl2, slo, shi);
   }
 #undef MGX_SUM_R
 #undef MGX_FETCH
-#undef MGX_COLOUR
+#undef MGX_BLK
+#undef MGX_RED
+#undef MGX_SET_BLK
+#undef MGX_SET_RED
 #undef MGX_STAGE
+#undef MGX_Q
 
   if (reduce) mgx_block_commit<NW + 1>((double)(err * err), slo, shi, ovf, reduce, res);
 }
@@ -457,7 +464,17 @@ __global__ __launch_bounds__((NW + 1) * 64) void k_fused_sweep(const T *__restri
   const int tx = lid % ntx, ty = (lid / ntx) % nty, tz = lid / (ntx * nty);
   const int tx0 = 1 + tx * 2 * TXP, ty0 = 1 + ty * TY;
   const int zc0 = 1 + tz * ZC, zc1 = min(zc0 + ZC - 1, g.n3);
-  mgx_fused_body<T, TY, BOXES, NW>(src, dst, g, p, bx, nb, tx0, ty0, zc0, zc1, reduce, res, lds, bl);
+  // parity of y + z (global) of the wave's first item on the first plane of the march, zc0 - 1
+  const int wave = threadIdx.x >> 6;
+  const bool halo = wave == NW;
+  const int p0 = (ty0 - 2 + (halo ? 0 : wave) + zc0 - 1 + g.z0) & 1;
+  if (halo) {
+    if (p0) mgx_fused_body<T, TY, BOXES, NW, 1, true>(src, dst, g, p, bx, nb, tx0, ty0, zc0, zc1, reduce, res, lds, bl);
+    else mgx_fused_body<T, TY, BOXES, NW, 0, true>(src, dst, g, p, bx, nb, tx0, ty0, zc0, zc1, reduce, res, lds, bl);
+  } else {
+    if (p0) mgx_fused_body<T, TY, BOXES, NW, 1, false>(src, dst, g, p, bx, nb, tx0, ty0, zc0, zc1, reduce, res, lds, bl);
+    else mgx_fused_body<T, TY, BOXES, NW, 0, false>(src, dst, g, p, bx, nb, tx0, ty0, zc0, zc1, reduce, res, lds, bl);
+  }
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -484,7 +501,7 @@ static int mgx_fused_make_plan(MgxFusedPlan &pl, const MgxGeom &g, const std::ve
   if (g.n1 >= 96 && g.n2 >= 40) { pl.ty = 20; pl.nw = 8; } else { pl.ty = 8; pl.nw = 4; }
   if (mgx_fused_ty > 0) {
     const int want = mgx_fused_ty * 100 + mgx_fused_nw;
-    if (want == 804 || want == 1604 || want == 1204 || want == 1208 || want == 2008 || want == 2808) { pl.ty = mgx_fused_ty; pl.nw = mgx_fused_nw; }
+    if (want == 804 || want == 1208 || want == 2008) { pl.ty = mgx_fused_ty; pl.nw = mgx_fused_nw; }
   }
   pl.ntx = (g.n1 + 2 * TXP - 1) / (2 * TXP);
   pl.nty = (g.n2 + pl.ty - 1) / pl.ty;
@@ -565,7 +582,9 @@ static int mgx_fused_launch_cfg(const MgxFusedPlan &pl, const T *src, T *dst, co
 // the box body keeps one bit per box in 32-bit sets
 template <typename T>
 static bool mgx_fused_supported(const MgxGeom &g, int nbox) {
-  return g.n1 >= 1 && g.n2 >= 1 && g.n3 >= 1 && nbox <= MGX_MAX_FUSED_BOXES;
+  // pairs are addressed by 32-bit byte offsets inside a plane
+  return g.n1 >= 1 && g.n2 >= 1 && g.n3 >= 1 && nbox <= MGX_MAX_FUSED_BOXES &&
+         (g.pz + g.front) * (long long)sizeof(T) < 0x7fffffffLL;
 }
 
 template <typename T>
@@ -573,11 +592,8 @@ static int mgx_fused_launch(const MgxFusedPlan &pl, const T *src, T *dst, const 
                             const MgxBox *bx, int nb, int reduce, u64 *res, hipStream_t st, hipStream_t aux,
                             hipEvent_t ev_fork, hipEvent_t ev_join) {
   switch (pl.ty * 100 + pl.nw) {
-    case 1604: return mgx_fused_launch_cfg<T, 16, 4>(pl, src, dst, g, p, bx, nb, reduce, res, st, aux, ev_fork, ev_join);
-    case 1204: return mgx_fused_launch_cfg<T, 12, 4>(pl, src, dst, g, p, bx, nb, reduce, res, st, aux, ev_fork, ev_join);
     case 1208: return mgx_fused_launch_cfg<T, 12, 8>(pl, src, dst, g, p, bx, nb, reduce, res, st, aux, ev_fork, ev_join);
     case 2008: return mgx_fused_launch_cfg<T, 20, 8>(pl, src, dst, g, p, bx, nb, reduce, res, st, aux, ev_fork, ev_join);
-    case 2808: return mgx_fused_launch_cfg<T, 28, 8>(pl, src, dst, g, p, bx, nb, reduce, res, st, aux, ev_fork, ev_join);
     default: return mgx_fused_launch_cfg<T, 8, 4>(pl, src, dst, g, p, bx, nb, reduce, res, st, aux, ev_fork, ev_join);
   }
 }

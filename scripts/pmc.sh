@@ -12,6 +12,7 @@ for grp in "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY 
            "SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS" \
            "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "GRBM_GUI_ACTIVE"; do
   i=$((i+1))
+  case " ${PMC_ONLY:-1 2 3 4 5 6} " in *" $i "*) ;; *) continue;; esac
   timeout -s KILL 120 rocprofv3 --pmc $grp --output-format csv -d $OUT/p$i -- python3 $R/scripts/quick_sweep_timing.py $ARGS > $OUT/p$i.log 2>&1 || { echo "pass $i failed"; tail -3 $OUT/p$i.log; exit 1; }
 done
 python3 - <<PY
