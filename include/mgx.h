@@ -99,7 +99,12 @@ int mgx_level_setup(mgx_level *lv, int init);
  * (black = odd x+y+z first, then red) are enqueued; the reductions named in
  * `reduce` (MGX_RED_ERR: max (vv-V)^2; MGX_RED_SUM: sum |V| over the interior,
  * i.e. the grid_sum that follows gs_step at m_gs_CDS.F90:206) are taken on the
- * LAST sweep and fetched with mgx_level_result.  Replaces m_gs_CDS.F90:202,241,272. */
+ * LAST sweep and fetched with mgx_level_result.  Replaces m_gs_CDS.F90:202,241,272.
+ * On a slab level one call takes ONE sweep (fused kernel): it reads local planes -1, 0, n3+1, n3+2
+ * as the caller left them and updates planes 1..n3; the caller then sends the new planes 1, 2 to
+ * the lower neighbour's n3+1, n3+2 and the new planes n3-1, n3 to the upper neighbour's -1, 0
+ * (mgx_level_plane_ptr; no other call is needed after such an exchange).  Reductions cover the
+ * slab's own planes. */
 int mgx_level_sweep(mgx_level *lv, int nsweeps, int reduce);
 /* one colour only (parity 1 = odd x+y+z, 0 = even), planes [zlo,zhi] (local, 1-based,
  * inclusive) — the building block for halo-exchange overlap across z-slabs.

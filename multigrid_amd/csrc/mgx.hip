@@ -410,7 +410,15 @@ extern "C" int mgx_level_sweep(mgx_level *lv, int nsweeps, int reduce) {
   if (nsweeps < 0) return fail(MGX_EINVAL, "mgx_level_sweep: nsweeps = %d", nsweeps);
   if (!lv->params_set) return fail(MGX_ESTATE, "mgx_level_sweep: mgx_level_set_params not called");
   if (!lv->defined) return fail(MGX_ESTATE, "mgx_level_sweep: level %d was released", lv->layer);
-  if (lv->g.n3 != lv->g.n3g) return fail(MGX_ESTATE, "mgx_level_sweep: slab levels are swept colour by colour (mgx_level_half_sweep)");
+  if (lv->g.n3 != lv->g.n3g) {
+    // a slab: the fused kernel reads halo planes -1, 0, n3+1, n3+2 as the caller left them; the in-place
+    // kernel would need the neighbour's black planes between the two colours
+    if (nsweeps > 1) return fail(MGX_ESTATE, "mgx_level_sweep: a slab takes one sweep per call (exchange the halo planes in between)");
+    if (C(lv)->kernel == MGX_KERNEL_TWO_PASS)
+      return fail(MGX_ESTATE, "mgx_level_sweep: the two-pass kernel sweeps a slab colour by colour (mgx_level_half_sweep)");
+    const bool ok = lv->elem == 4 ? mgx_fused_supported<float>(lv->g, lv->nbox) : mgx_fused_supported<double>(lv->g, lv->nbox);
+    if (!ok) return fail(MGX_ELIMIT, "mgx_level_sweep: the fused kernel does not take this level; sweep the slab with mgx_level_half_sweep");
+  }
   TRY(set_device(C(lv)));
   return lv->elem == 4 ? do_sweeps<float>(lv, nsweeps, reduce) : do_sweeps<double>(lv, nsweeps, reduce);
 }

@@ -1,0 +1,160 @@
+"""z-slab decomposition of one level over the ranks of a torch.distributed group
+(one process per GPU; backend "nccl" = RCCL over xGMI on the GPU box, "gloo" in CPU tests).
+
+The reference sweeps a level with OpenMP threads over one address space
+(src/m_gs_CDS.F90:317-345); across GPUs the same red-black sweep needs exactly one exchange
+per sweep: rank r owns the global planes z0+1 .. z0+n3 of the level and keeps two halo planes
+on either side.  One fused sweep (black on planes 0 .. n3+1 from the old values, then red on
+1 .. n3) is local; afterwards the new planes 1, 2 go to the lower neighbour's n3+1, n3+2 and
+the new planes n3-1, n3 to the upper neighbour's -1, 0.  Whole padded planes travel, so the
+frozen x/y ghost columns of the neighbour's planes come along.  The global z ghost planes
+(0 and n3g+1) stay as grid_setup left them, like every ghost in the reference
+(t_mg.f90:465-588 runs only at set-up); only a periodic z boundary needs the far rank's plane
+at set-up time.
+
+Reductions: max (vv-V)^2 is a MAX all-reduce; sum |V| is the exact integer sum
+(units of 2^-72), sent as four 32-bit digits in int64 and added with a SUM all-reduce, so the
+result has the same bits for any number of ranks.
+
+The level object behind a slab only needs: setup(init), sweep(1, reduce), result(),
+halo_written(), plane_tensor(z, count); multigrid_amd.lib.DeviceLevel provides them on the GPU.
+"""
+from __future__ import annotations
+
+from typing import Callable, List, Optional, Tuple
+
+import numpy as np
+
+from . import grid as G
+from . import lib
+
+SUM_UNITS = 1 << 72
+
+
+def split_planes(n3: int, world: int) -> List[Tuple[int, int]]:
+    """(z0, n3_local) of every rank: contiguous, sizes differ by at most one plane"""
+    base, rem = divmod(int(n3), int(world))
+    out, z0 = [], 0
+    for r in range(world):
+        k = base + (1 if r < rem else 0)
+        out.append((z0, k))
+        z0 += k
+    return out
+
+
+class _DevicePlanes:
+    """a run of planes of a device level as a zero-copy torch uint8 tensor (__cuda_array_interface__)"""
+
+    def __init__(self, ptr: int, nbytes: int):
+        self.__cuda_array_interface__ = {"shape": (int(nbytes),), "typestr": "|u1", "data": (int(ptr), False),
+                                         "version": 2, "strides": None}
+
+
+def device_plane_tensor(lv: "lib.DeviceLevel", z: int, count: int):
+    import torch
+    ptr, nbytes = lv.plane_ptr(z, count)
+    return torch.as_tensor(_DevicePlanes(ptr, nbytes), device=torch.device("cuda", lv.ctx.device))
+
+
+class SlabLevel:
+    """one rank's slab of a level + the halo exchange and the all-reduced reductions"""
+
+    def __init__(self, ctx, top: G.MgGrid, rank: int, world: int, group=None,
+                 level_factory: Optional[Callable] = None, plane_tensor: Optional[Callable] = None):
+        import torch.distributed as dist
+        self.dist = dist
+        self.rank, self.world, self.group = int(rank), int(world), group
+        self.grid = top
+        n = [int(v) for v in top.n]
+        parts = split_planes(n[2], world)
+        self.z0, self.n3 = parts[rank]
+        if min(k for _, k in parts) < 2 and world > 1:
+            raise ValueError(f"level of depth {n[2]} over {world} ranks: every slab needs at least 2 planes")
+        self.n_global = tuple(n)
+        make = level_factory if level_factory is not None else ctx.level
+        self.lv = make(top.layer, n, top.dtype, self.z0, self.n3)
+        self.lv.set_params(top.sor, [float(v) for v in top.a], top.bc6())
+        self.lv.set_boxes(*G.box_table(top))
+        self._plane_tensor = plane_tensor if plane_tensor is not None else device_plane_tensor
+        self.lower = rank - 1 if rank > 0 else None
+        self.upper = rank + 1 if rank < world - 1 else None
+        self.periodic_z = top.bc6()[4] == lib.BC_PERIODIC or top.bc6()[5] == lib.BC_PERIODIC
+        self.reduce = lib.RED_ERR | lib.RED_SUM
+
+    # ---- communication -------------------------------------------------------------------------
+    def planes(self, z: int, count: int):
+        return self._plane_tensor(self.lv, z, count)
+
+    def _run(self, ops):
+        if ops:
+            for w in self.dist.batch_isend_irecv(ops):
+                w.wait()
+
+    def exchange_halos(self):
+        """new planes 1,2 -> lower neighbour's n3+1,n3+2; new planes n3-1,n3 -> upper neighbour's -1,0"""
+        if self.world == 1:
+            return
+        P, d, ops = self.dist.P2POp, self.dist, []
+        # every rank lists its ops lower-neighbour first: matching order on both sides of a link
+        if self.lower is not None:
+            ops.append(P(d.isend, self.planes(1, 2), self.lower, self.group))
+            ops.append(P(d.irecv, self.planes(-1, 2), self.lower, self.group))
+        if self.upper is not None:
+            ops.append(P(d.irecv, self.planes(self.n3 + 1, 2), self.upper, self.group))
+            ops.append(P(d.isend, self.planes(self.n3 - 1, 2), self.upper, self.group))
+        self._run(ops)
+
+    def _exchange_periodic_ghosts(self):
+        """grid_setup's periodic C faces (t_mg.f90:553-583): ghost plane 0 = plane n3g, ghost plane n3g+1 = plane 1,
+        whole planes including the x/y ghosts the A and B faces filled before"""
+        if self.world == 1:
+            return
+        bc = self.grid.bc6()
+        P, d, ops = self.dist.P2POp, self.dist, []
+        first, last = 0, self.world - 1
+        if bc[4] == lib.BC_PERIODIC:            # C0: plane 0 on the first rank <- plane n3g on the last
+            if self.rank == last:
+                ops.append(P(d.isend, self.planes(self.n3, 1), first, self.group))
+            if self.rank == first:
+                ops.append(P(d.irecv, self.planes(0, 1), last, self.group))
+        self._run(ops)
+        ops = []
+        if bc[5] == lib.BC_PERIODIC:            # C1: plane n3g+1 on the last rank <- plane 1 on the first
+            if self.rank == first:
+                ops.append(P(d.isend, self.planes(1, 1), last, self.group))
+            if self.rank == last:
+                ops.append(P(d.irecv, self.planes(self.n3 + 1, 1), first, self.group))
+        self._run(ops)
+
+    # ---- the level operators -------------------------------------------------------------------
+    def setup(self, init: bool):
+        """grid_setup on every slab, then the planes only another rank can supply"""
+        self.lv.setup(init)
+        if self.periodic_z:
+            self._exchange_periodic_ghosts()
+        self.exchange_halos()
+        self.lv.halo_written()
+
+    def sweep(self, reduce: Optional[int] = None):
+        """one red-black sweep of the whole level (gs_step, m_gs_CDS.F90:296-315)"""
+        self.lv.sweep(1, self.reduce if reduce is None else reduce)
+        self.exchange_halos()
+
+    def result(self):
+        """(max (vv-V)^2, sum|V|, exact sum in units of 2^-72) over the WHOLE level, identical on every rank"""
+        e2, s, units = self.lv.result()
+        if self.world == 1:
+            return e2, s, units
+        import torch
+        dev = self.planes(1, 1).device
+        bad = 1.0 if (s != s) else 0.0
+        mx = torch.tensor([e2, bad], dtype=torch.float64, device=dev)
+        self.dist.all_reduce(mx, op=self.dist.ReduceOp.MAX, group=self.group)
+        digits = torch.tensor([(units >> (32 * i)) & 0xFFFFFFFF for i in range(4)], dtype=torch.int64, device=dev)
+        self.dist.all_reduce(digits, op=self.dist.ReduceOp.SUM, group=self.group)
+        total = sum(int(v) << (32 * i) for i, v in enumerate(digits.tolist()))
+        e2g, badg = mx.tolist()
+        return e2g, (float("nan") if badg else total / SUM_UNITS), total
+
+    def download(self) -> np.ndarray:
+        return self.lv.download()

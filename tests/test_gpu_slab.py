@@ -1,0 +1,88 @@
+"""GPU: z-slab levels (mgx_level_create_slab + one fused sweep per call + halo planes copied by the caller) against
+the undivided level on the same GPU and against the oracle, bit for bit.  Slabs start at odd and even z."""
+import os
+import sys
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+pytestmark = pytest.mark.gpu
+
+
+def _levels(ctx, n, dtype, parts, bc, boxes, sor=1.6):
+    from multigrid_amd import lib
+    out = []
+    for z0, k in parts:
+        lv = ctx.level(1, n, dtype, z0, k)
+        lv.set_params(sor, (0.3, 0.3, 0.4), bc)
+        lv.set_boxes(*boxes)
+        out.append(lv)
+    return out
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("parts", [[(0, 13), (13, 11)], [(0, 8), (8, 7), (15, 9)]])
+def test_slab_sweeps_equal_undivided(dtype, parts):
+    import torch
+    from multigrid_amd import lib, slab
+    from oracle import oracle as orc
+    n = (150, 45, 24)
+    bc = (1, 1, 1, 1, 3, 2)
+    place = np.array([[40, 110, 10, 30, 1, 2], [40, 110, 10, 30, 23, 24], [60, 90, 15, 25, 3, 22]], dtype=np.int32)
+    boxes = (place, [0.5, -0.5, 0.0], [1.0, 1.0, 3.0], [1, 1, 0])
+    ctx = lib.Context(0, None)
+    whole = _levels(ctx, n, dtype, [(0, n[2])], bc, boxes)[0]
+    slabs = _levels(ctx, n, dtype, parts, bc, boxes)
+    rng = np.random.default_rng(5)
+    V0 = rng.standard_normal((n[2] + 2, n[1] + 2, n[0] + 2)).astype(dtype)
+    whole.upload(V0)
+    whole.setup(False)
+    L = orc.Level(n=n, bc=bc, sor=1.6, a=(0.3, 0.3, 0.4),
+                  boxes=[orc.Box(tuple(int(v) for v in p), v_, r_, bool(c_)) for p, v_, r_, c_ in zip(place, *boxes[1:])])
+    Vref = V0.copy()
+    orc.setup(L, Vref, False)
+    assert np.array_equal(whole.download().view(np.uint8), Vref.view(np.uint8))
+
+    def exchange():
+        ctx.sync()
+        for lo, up in zip(slabs[:-1], slabs[1:]):
+            slab.device_plane_tensor(up, -1, 2).copy_(slab.device_plane_tensor(lo, lo.n3_local - 1, 2))
+            slab.device_plane_tensor(lo, lo.n3_local + 1, 2).copy_(slab.device_plane_tensor(up, 1, 2))
+        torch.cuda.synchronize()
+
+    for lv, (z0, k) in zip(slabs, parts):
+        lv.upload(np.ascontiguousarray(V0[z0:z0 + k + 2]))
+        lv.setup(False)
+    exchange()
+    for lv in slabs:
+        lv.halo_written()
+    for it in range(4):
+        e_ref = orc.sweep(L, Vref, orc.ORDER_RB)
+        s_ref, u_ref = orc.abs_sum_exact(L, Vref)
+        whole.sweep(1, 3)
+        e_w, s_w, u_w = whole.result()
+        assert (e_w, u_w) == (e_ref, u_ref)
+        for lv in slabs:
+            lv.sweep(1, 3)
+        res = [lv.result() for lv in slabs]
+        exchange()
+        assert max(r[0] for r in res) == e_ref
+        assert sum(r[2] for r in res) == u_ref
+        for lv, (z0, k) in zip(slabs, parts):
+            got = lv.download()
+            assert np.array_equal(got.view(np.uint8), Vref[z0:z0 + k + 2].view(np.uint8)), f"sweep {it} slab z0={z0}"
+    ctx.close()
+
+
+def test_slab_two_pass_kernel_refused():
+    from multigrid_amd import lib
+    ctx = lib.Context(0, None)
+    ctx.set_kernel(lib.KERNEL_TWO_PASS)
+    lv = _levels(ctx, (16, 16, 16), np.float64, [(0, 8)], (2,) * 6, (np.zeros((0, 6), np.int32), [], [], []))[0]
+    lv.setup(True)
+    with pytest.raises(lib.MgxError):
+        lv.sweep(1, 0)
+    ctx.close()

@@ -1,0 +1,140 @@
+"""Multi-rank path on CPU: multigrid_amd.slab over gloo (world_size 2 and 3) with the oracle-backed fake level.
+After every sweep each rank's slab must equal, bit for bit, the same planes of the oracle's red-black sweep of
+the undivided level, and the all-reduced reductions must equal the undivided ones."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+CASES = {
+    "mixed_bc_boxes": dict(text="""
+cell 2.4 2.0 2.2
+max-layers 1
+boxes 3
+begin layers
+  sor 1.7
+  tol 1.e-6
+  mesh-size 24 20 22
+  bc a periodic
+  bc b periodic
+  bc c- neumann
+  bc c+ dirichlet
+end layers
+begin box
+  llc 0.9 0.8 0.2
+  cell 0.6 0.5 1.7
+  value 0.
+  rho 3.
+  constant false
+end box
+begin box
+  llc 0.6 0.5 0.
+  cell 1.2 1.0 0.2
+  value 0.5
+end box
+begin box
+  llc 0.6 0.5 2.0
+  cell 1.2 1.0 0.2
+  value -0.5
+end box
+""", dtype=np.float64, sweeps=5, init=True),
+    "periodic_z_random_f32": dict(text="""
+cell 1.3 1.7 1.1
+max-layers 1
+boxes 1
+precision single
+begin layers
+  sor 1.5
+  tol 1.e-4
+  mesh-size 13 17 11
+  bc a neumann
+  bc b dirichlet
+  bc c periodic
+end layers
+begin box
+  llc 0.3 0.4 0.4
+  cell 0.5 0.6 0.4
+  value 1.25
+end box
+""", dtype=np.float32, sweeps=4, init=False),
+}
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _top(case):
+    from multigrid_amd import mgio
+    text = "\n".join(l for l in case["text"].splitlines() if not l.startswith("precision"))
+    return mgio.iomg_read(mgio.MgIO(text=text), dtype=case["dtype"])
+
+
+def _worker(rank, world, port, name, outdir):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        from multigrid_amd import slab
+        from tests import slab_fake
+        from tests.helpers import oracle_levels
+        from oracle import oracle as orc
+        case = CASES[name]
+        top = _top(case)
+        dt = np.dtype(case["dtype"])
+        L = oracle_levels(top)[0]
+        rng = np.random.default_rng(11)
+        V0 = rng.standard_normal(L.shape()).astype(dt)
+        Vref = np.zeros(L.shape(), dtype=dt) if case["init"] else V0.copy()
+        orc.setup(L, Vref, case["init"])
+
+        def factory(layer, n, dtype, z0, n3_local):
+            return slab_fake.FakeSlabLevel(layer, n, dtype, z0, n3_local, global_init=None if case["init"] else V0)
+
+        sl = slab.SlabLevel(None, top, rank, world, level_factory=factory, plane_tensor=slab_fake.plane_tensor)
+        sl.setup(case["init"])
+        z0, n3 = sl.z0, sl.n3
+        mine = sl.download()
+        assert np.array_equal(mine[1:-1].view(np.uint8), Vref[z0 + 1:z0 + n3 + 1].view(np.uint8)), "setup: owned planes"
+        # ghosts / halos next to the slab must be what the undivided level holds there
+        assert np.array_equal(mine[0].view(np.uint8), Vref[z0].view(np.uint8)), "setup: plane below"
+        assert np.array_equal(mine[-1].view(np.uint8), Vref[z0 + n3 + 1].view(np.uint8)), "setup: plane above"
+        for it in range(case["sweeps"]):
+            e_ref = orc.sweep(L, Vref, orc.ORDER_RB)
+            s_ref, u_ref = orc.abs_sum_exact(L, Vref)
+            sl.sweep()
+            e2, s, units = sl.result()
+            mine = sl.download()
+            assert np.array_equal(mine[1:-1].view(np.uint8), Vref[z0 + 1:z0 + n3 + 1].view(np.uint8)), f"sweep {it}: owned planes"
+            assert np.array_equal(mine[0].view(np.uint8), Vref[z0].view(np.uint8)), f"sweep {it}: plane below"
+            assert np.array_equal(mine[-1].view(np.uint8), Vref[z0 + n3 + 1].view(np.uint8)), f"sweep {it}: plane above"
+            assert units == u_ref and s == s_ref, f"sweep {it}: sum {s} vs {s_ref}"
+            assert e2 == e_ref, f"sweep {it}: err {e2} vs {e_ref}"
+        open(os.path.join(outdir, f"ok{rank}"), "w").write("ok")
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world", [2, 3])
+@pytest.mark.parametrize("name", sorted(CASES))
+def test_slab_sweeps_match_undivided_level(name, world, tmp_path):
+    mp.spawn(_worker, args=(world, _free_port(), name, str(tmp_path)), nprocs=world, join=True)
+    assert all((tmp_path / f"ok{r}").exists() for r in range(world))
+
+
+def test_split_planes():
+    from multigrid_amd import slab
+    assert slab.split_planes(11, 3) == [(0, 4), (4, 4), (8, 3)]
+    assert slab.split_planes(512, 8)[-1] == (448, 64)
