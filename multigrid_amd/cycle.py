@@ -92,6 +92,10 @@ class Solver:
         g.dev.sweep(nsteps, lib.RED_ERR | (lib.RED_SUM if want_sum else 0))
         e2, s, _ = g.dev.result()
         g.err = float(np.sqrt(self.t(e2)))
+        if want_sum and s != s:
+            # the reference would carry the overflowing sum through its `do while (tol > ...)` tests, which a NaN
+            # ends as if converged (m_gs_CDS.F90:200-210); a diverging iteration is reported instead
+            raise G.MgStop(f"layer {g.layer}: |V| reached 2^20 or is not finite after {g.itt} sweeps: the iteration diverges")
         return self.t(s) if want_sum else None
 
     def record(self, g, kind, tol, s):

@@ -12,13 +12,26 @@ pytestmark = pytest.mark.gpu
 
 SOLVES = ["solve_64_bu", "solve_80_bu", "solve_80_v", "solve_64x48x80_v_half"]
 
+# The reference's V-cycle of solve_80_v runs at sor 1.8; in red-black order that over-relaxation makes the cycle
+# (restriction and prolongation overwrite the levels) diverge, in the oracle exactly as on the GPU.  The parity
+# comparison therefore runs this input at sor 1.6; the divergent run has a test of its own below.
+SOR_OVERRIDE = {"solve_80_v": ("sor 1.8", "sor 1.6")}
+
+
+def _input(name, prec):
+    text = str(load(f"{name}_{prec}")["input"])
+    if name in SOR_OVERRIDE:
+        old, new = SOR_OVERRIDE[name]
+        assert old in text
+        text = text.replace(old, new)
+    return text
+
 
 @pytest.mark.parametrize("kernel", [1, 2])
 @pytest.mark.parametrize("prec", ["f32", "f64"])
 @pytest.mark.parametrize("name", SOLVES)
 def test_solve_matches_oracle(name, prec, kernel):
-    g = load(f"{name}_{prec}")
-    IO = mgio.MgIO(text=str(g["input"]))
+    IO = mgio.MgIO(text=_input(name, prec))
     top = mgio.iomg_read(IO, dtype=DT[prec])
     method = mgio.read_method(IO)
     V, hist, per = orc.solve(oracle_levels(top), method, DT[prec], order=orc.ORDER_RB, sum_mode=orc.SUM_EXACT)
@@ -35,5 +48,24 @@ def test_solve_matches_oracle(name, prec, kernel):
         for f in ("tol", "sum", "err"):
             assert np.array_equal(h[f], hist[f]), f
         assert bits_equal(W, V)
+    finally:
+        s.close()
+
+
+def test_divergent_solve_is_reported():
+    """sor 1.8 in red-black order: the oracle's sum overflows its exact range (NaN); the library refuses to return a
+    sum once a value reaches 2^20 and the host stops with that error instead of iterating on garbage"""
+    from multigrid_amd import lib
+    text = str(load("solve_80_v_f64")["input"])
+    IO = mgio.MgIO(text=text)
+    top = mgio.iomg_read(IO, dtype=np.float64)
+    method = mgio.read_method(IO)
+    _, hist, _ = orc.solve(oracle_levels(top), method, np.float64, order=orc.ORDER_RB, sum_mode=orc.SUM_EXACT)
+    assert np.isnan(hist["sum"]).any()
+    s = cycle.Solver(top)
+    try:
+        from multigrid_amd import grid as G
+        with pytest.raises((lib.MgxError, G.MgStop)):
+            s.mg_gs_cds(method)
     finally:
         s.close()
