@@ -401,3 +401,42 @@ def vmg_name(filename: str) -> str:
     """mg_save (m_mg_save.F90:35-84) strips the extension and mg_binary appends '.VMG'"""
     i = filename.find(".")
     return (filename[:i] if i > 0 else filename) + ".VMG"
+
+
+def write_host_case(top: G.MgGrid, method: int, path: str, kernel: int = 0) -> None:
+    """the hierarchy as the Fortran driver multigrid_amd/fortran/mg_gpu reads it (sizes, sweep parameters, boundary
+    codes and box index ranges of every level: the fields init_grid / grid_add_box fill, t_mg.f90:22-72)"""
+    levels = list(top.levels())
+    with open(path, "w") as f:
+        f.write(f"{len(levels)} {int(method)} {int(kernel)}\n")
+        for g in levels:
+            f.write(" ".join(str(int(v)) for v in g.n) + "\n")
+            f.write(f"{float(g.sor)!r}\n")
+            f.write(" ".join(repr(float(v)) for v in g.a) + "\n")
+            f.write(f"{float(g.tol)!r}\n")
+            f.write(f"{int(g.steps)}\n")
+            f.write(" ".join(str(int(v)) for v in g.bc6()) + "\n")
+            f.write(f"{int(g.RES_method)} {int(g.PRO_method)}\n")
+            f.write(f"{int(bool(g.enabled))}\n")
+            place, val, rho, const = G.box_table(g)
+            f.write(f"{len(val)}\n")
+            for p, v, r, c in zip(place, val, rho, const):
+                f.write(" ".join(str(int(x)) for x in p) + f" {float(v)!r} {float(r)!r} {int(c)}\n")
+
+
+def read_host_result(path: str, nlevels: int, shape, dtype):
+    """history, sweeps per level and top-level field written by mg_gpu"""
+    raw = open(path, "rb").read()
+    n = int(np.frombuffer(raw, "<i4", 1)[0])
+    off = 4
+    out = {}
+    for name in ("layer", "kind", "itt"):
+        out[name] = np.frombuffer(raw, "<i4", n, off)
+        off += 4 * n
+    for name in ("tol", "sum", "err"):
+        out[name] = np.frombuffer(raw, "<f8", n, off)
+        off += 8 * n
+    per = np.frombuffer(raw, "<i4", nlevels, off)
+    off += 4 * nlevels
+    V = np.frombuffer(raw, np.dtype(dtype), int(np.prod(shape)), off).reshape(shape)
+    return out, [int(v) for v in per], V
