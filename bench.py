@@ -234,7 +234,7 @@ def main():
             g.itt = 0
         solver.history = []
         solver.total_sweeps = 0
-        solver.print_sums = True
+        solver.print_sums = False     # the sums gs_V evaluates only to print them (m_gs_CDS.F90:238,245,269,275)
         torch.cuda.synchronize()
         tv0 = time.perf_counter()
         status = "converged"

@@ -66,6 +66,7 @@ struct mgx_level {
   int cur = 0;
   bool shell_synced = false;   // buf[1-cur] holds the same ghost shell as buf[cur]
   bool defined = false;        // field content is meaningful
+  bool zero_pending = false;   // brought back but not yet zero-filled: the next reader fills, a full overwrite skips it
   // parameters
   double sor = 1.8;
   double a[3] = {1.0 / 3, 1.0 / 3, 1.0 / 3};
@@ -77,6 +78,18 @@ struct mgx_level {
   long long count_cache = -1;
   u64 *d_res = nullptr;        // MGX_RES_WORDS words
   MgxFusedPlan plan;           // tile lists of the fused sweep (rebuilt when the boxes change)
+  std::vector<struct MgxTransferPlan *> transfers;   // index tables of transfers INTO this level, by source geometry
+};
+
+// device index tables of one (source geometry, method, direction) transfer into a level; they depend on the
+// two geometries only, so they are built on first use and kept until the level is destroyed
+struct MgxTransferPlan {
+  int n_src[3] = {0, 0, 0};     // global size of the source level
+  int method = 0;
+  bool restrict_ = false;
+  int *d_tab = nullptr;         // restriction: mx | my | mz (forward maps); prolongation: rx | ry | rz as (lo, hi) pairs
+  size_t off_y = 0, off_z = 0;  // element offsets of the y and z tables inside d_tab
+  int cz_lo = 0, cz_hi = -1;    // prolongation: global child planes that feed this (slab of the) parent
 };
 
 static inline mgx_ctx *C(mgx_level *lv) { return lv->ctx; }
@@ -226,6 +239,7 @@ extern "C" int mgx_level_destroy(mgx_level *lv) {
   (void)hipFree(lv->d_res);
   if (lv->d_boxes) (void)hipFree(lv->d_boxes);
   if (lv->plan.d_tiles) (void)hipFree(lv->plan.d_tiles);
+  for (MgxTransferPlan *t : lv->transfers) { (void)hipFree(t->d_tab); delete t; }
   delete lv;
   return MGX_OK;
 }
@@ -233,9 +247,17 @@ extern "C" int mgx_level_destroy(mgx_level *lv) {
 extern "C" int mgx_level_bring_back(mgx_level *lv) {
   if (!lv) return fail(MGX_EINVAL, "mgx_level_bring_back: NULL level");
   TRY(set_device(C(lv)));
-  HIP_TRY(hipMemsetAsync(lv->buf[lv->cur], 0, (size_t)lv->elems * lv->elem, C(lv)->stream));
+  lv->zero_pending = true;      // prolongation into a whole level overwrites every cell: it skips the fill
   lv->shell_synced = false;
   lv->defined = true;
+  return MGX_OK;
+}
+
+// the zero fill grid_bring_back promised, before anything reads the field
+static int materialize(mgx_level *lv) {
+  if (!lv->zero_pending) return MGX_OK;
+  HIP_TRY(hipMemsetAsync(lv->buf[lv->cur], 0, (size_t)lv->elems * lv->elem, C(lv)->stream));
+  lv->zero_pending = false;
   return MGX_OK;
 }
 
@@ -319,7 +341,8 @@ static int do_setup(mgx_level *lv, int init) {
   const MgxGeom &g = lv->g;
   hipStream_t st = C(lv)->stream;
   T *V = (T *)lv->buf[lv->cur];
-  if (init) HIP_TRY(hipMemsetAsync(V, 0, (size_t)lv->elems * lv->elem, st));
+  if (init) lv->zero_pending = true;      // V = 0 (t_mg.f90:473-479)
+  TRY(materialize(lv));
   bool any_const = false;
   for (const MgxBox &b : lv->boxes) any_const |= b.constant != 0;
   if (any_const) {
@@ -420,6 +443,7 @@ extern "C" int mgx_level_sweep(mgx_level *lv, int nsweeps, int reduce) {
     if (!ok) return fail(MGX_ELIMIT, "mgx_level_sweep: the fused kernel does not take this level; sweep the slab with mgx_level_half_sweep");
   }
   TRY(set_device(C(lv)));
+  TRY(materialize(lv));
   return lv->elem == 4 ? do_sweeps<float>(lv, nsweeps, reduce) : do_sweeps<double>(lv, nsweeps, reduce);
 }
 
@@ -430,6 +454,7 @@ extern "C" int mgx_level_half_sweep(mgx_level *lv, int parity, int32_t zlo, int3
   if (!lv->params_set) return fail(MGX_ESTATE, "mgx_level_half_sweep: mgx_level_set_params not called");
   if (zlo > zhi) return MGX_OK;
   TRY(set_device(C(lv)));
+  TRY(materialize(lv));
   return lv->elem == 4 ? launch_half<float>(lv, parity, zlo, zhi, reduce) : launch_half<double>(lv, parity, zlo, zhi, reduce);
 }
 
@@ -485,6 +510,7 @@ extern "C" int mgx_level_abs_sum_limbs(mgx_level *lv, uint64_t limbs[2]) {
   if (!lv || !limbs) return fail(MGX_EINVAL, "mgx_level_abs_sum_limbs: NULL argument");
   if (!lv->defined) return fail(MGX_ESTATE, "mgx_level_abs_sum: level %d was released", lv->layer);
   TRY(set_device(C(lv)));
+  TRY(materialize(lv));
   TRY(reset_result(lv));
   TRY(lv->elem == 4 ? launch_abs_sum<float>(lv) : launch_abs_sum<double>(lv));
   double s;
@@ -575,33 +601,6 @@ static int g2g(int n1, int i1, int n2) {                 // t_mg_interp.f90:995-
   return (int)std::max(1LL, std::min(v, (long long)n2));
 }
 
-struct DevTable {
-  int *d = nullptr;
-  ~DevTable() { if (d) (void)hipFree(d); }
-};
-
-static int upload_table(const std::vector<int> &h, DevTable &t, hipStream_t st) {
-  HIP_TRY(hipMalloc((void **)&t.d, sizeof(int) * h.size()));
-  HIP_TRY(hipMemcpyAsync(t.d, h.data(), sizeof(int) * h.size(), hipMemcpyHostToDevice, st));
-  return MGX_OK;
-}
-
-template <typename T>
-static int launch_transfer(bool restrict_, bool half, mgx_level *src, mgx_level *dst, const int *mx, const int *my,
-                           const int *mz) {
-  const MgxGeom &gd = dst->g;
-  dim3 grid((gd.n1 + 63) / 64, (gd.n2 + 3) / 4, gd.n3);
-  hipStream_t st = C(dst)->stream;
-  const T *s = (const T *)src->buf[src->cur];
-  T *d = (T *)dst->buf[dst->cur];
-  if (restrict_ && half) hipLaunchKernelGGL((k_transfer<T, true, true>), grid, dim3(256), 0, st, s, src->g, d, gd, mx, my, mz);
-  else if (restrict_) hipLaunchKernelGGL((k_transfer<T, false, true>), grid, dim3(256), 0, st, s, src->g, d, gd, mx, my, mz);
-  else if (half) hipLaunchKernelGGL((k_transfer<T, true, false>), grid, dim3(256), 0, st, s, src->g, d, gd, mx, my, mz);
-  else hipLaunchKernelGGL((k_transfer<T, false, false>), grid, dim3(256), 0, st, s, src->g, d, gd, mx, my, mz);
-  HIP_TRY(hipGetLastError());
-  return MGX_OK;
-}
-
 static int check_pair(const char *who, mgx_level *a, mgx_level *b, int method) {
   if (!a || !b) return fail(MGX_EINVAL, "%s: NULL level", who);
   if (a->ctx != b->ctx) return fail(MGX_EINVAL, "%s: levels belong to different contexts", who);
@@ -623,30 +622,117 @@ static int check_z_reach(const char *who, const std::vector<int> &mz, const mgx_
   return MGX_OK;
 }
 
+// (lo, hi) of the destination indices fed by each source index of a monotone forward map m[1..nd] -> [1..ns]
+static void invert_map(const std::vector<int> &m, int nd, int ns, std::vector<int> &r) {
+  r.assign(2 * (size_t)(ns + 2), 0);
+  for (int c = 0; c <= ns + 1; ++c) { r[2 * c] = 1; r[2 * c + 1] = 0; }      // empty: lo > hi
+  for (int d = 1; d <= nd; ++d) {
+    const int c = m[d];
+    if (r[2 * c] > r[2 * c + 1]) { r[2 * c] = d; r[2 * c + 1] = d; }
+    else { r[2 * c] = std::min(r[2 * c], d); r[2 * c + 1] = std::max(r[2 * c + 1], d); }
+  }
+}
+
+// find or build the index tables of a transfer from `src` into `dst`
+static int transfer_plan(const char *who, bool restrict_, mgx_level *src, mgx_level *dst, int method, MgxTransferPlan **out) {
+  const MgxGeom &gs = src->g, &gd = dst->g;
+  for (MgxTransferPlan *t : dst->transfers)
+    if (t->restrict_ == restrict_ && t->method == method && t->n_src[0] == gs.n1 && t->n_src[1] == gs.n2 &&
+        t->n_src[2] == gs.n3g) {
+      *out = t;
+      return MGX_OK;
+    }
+  // forward maps destination index -> source index, exactly as the reference's loops run
+  std::vector<int> mx(gd.n1 + 2, 0), my(gd.n2 + 2, 0), mz(gd.n3g + 2, 0);
+  if (restrict_) {                        // dst = child, src = parent
+    for (int cz = 1; cz <= gd.n3g; ++cz) mz[cz] = g2g(gd.n3g, cz, gs.n3g);            // t_mg_interp.f90:153,244
+    if (method == MGX_INTERP_HALF) {                                                   // :247-252
+      for (int cx = 1; cx <= gd.n1; ++cx) mx[cx] = g2g(gd.n1, cx, gs.n1);
+      for (int cy = 1; cy <= gd.n2; ++cy) my[cy] = g2g(gd.n2, cy, gs.n2);
+    } else {                                                                           // :156-161, last writer wins
+      for (int x = 2; x <= gs.n1; x += 2) mx[g2g(gs.n1, x, gd.n1)] = x;
+      for (int y = 2; y <= gs.n2; y += 2) my[g2g(gs.n2, y, gd.n2)] = y;
+    }
+  } else {                                // dst = parent, src = child
+    for (int px = 1; px <= gd.n1; ++px) mx[px] = g2g(gd.n1, px, gs.n1);               // t_mg_interp.f90:334,426
+    for (int py = 1; py <= gd.n2; ++py) my[py] = g2g(gd.n2, py, gs.n2);               // :330,422
+    for (int pz = 1; pz <= gd.n3g; ++pz) mz[pz] = g2g(gd.n3g, pz, gs.n3g);            // :326,418
+  }
+  TRY(check_z_reach(who, mz, src, dst));
+  MgxTransferPlan *t = new MgxTransferPlan();
+  t->n_src[0] = gs.n1; t->n_src[1] = gs.n2; t->n_src[2] = gs.n3g;
+  t->method = method;
+  t->restrict_ = restrict_;
+  std::vector<int> tab;
+  if (restrict_) {
+    tab = mx;
+    t->off_y = tab.size(); tab.insert(tab.end(), my.begin(), my.end());
+    t->off_z = tab.size(); tab.insert(tab.end(), mz.begin(), mz.end());
+  } else {
+    std::vector<int> rx, ry, rz;
+    invert_map(mx, gd.n1, gs.n1, rx);
+    invert_map(my, gd.n2, gs.n2, ry);
+    invert_map(mz, gd.n3g, gs.n3g, rz);
+    tab = rx;
+    t->off_y = tab.size(); tab.insert(tab.end(), ry.begin(), ry.end());
+    t->off_z = tab.size(); tab.insert(tab.end(), rz.begin(), rz.end());
+    t->cz_lo = mz[gd.z0 + 1];
+    t->cz_hi = mz[gd.z0 + gd.n3];
+  }
+  hipStream_t st = C(dst)->stream;
+  if (hipMalloc((void **)&t->d_tab, sizeof(int) * tab.size()) != hipSuccess) { delete t; return fail(MGX_ENOMEM, "%s: index tables", who); }
+  if (hipMemcpyAsync(t->d_tab, tab.data(), sizeof(int) * tab.size(), hipMemcpyHostToDevice, st) != hipSuccess ||
+      hipStreamSynchronize(st) != hipSuccess) {      // `tab` goes out of scope
+    (void)hipFree(t->d_tab);
+    delete t;
+    return fail(MGX_EHIP, "%s: index table upload", who);
+  }
+  dst->transfers.push_back(t);
+  *out = t;
+  return MGX_OK;
+}
+
+template <typename T>
+static int launch_restrict(bool half, mgx_level *src, mgx_level *dst, const MgxTransferPlan *t) {
+  const MgxGeom &gd = dst->g;
+  dim3 grid((gd.n1 + 63) / 64, (gd.n2 + 3) / 4, gd.n3);
+  hipStream_t st = C(dst)->stream;
+  const T *s = (const T *)src->buf[src->cur];
+  T *d = (T *)dst->buf[dst->cur];
+  const int *mx = t->d_tab, *my = t->d_tab + t->off_y, *mz = t->d_tab + t->off_z;
+  if (half) hipLaunchKernelGGL((k_transfer<T, true, true>), grid, dim3(256), 0, st, s, src->g, d, gd, mx, my, mz);
+  else hipLaunchKernelGGL((k_transfer<T, false, true>), grid, dim3(256), 0, st, s, src->g, d, gd, mx, my, mz);
+  HIP_TRY(hipGetLastError());
+  return MGX_OK;
+}
+
+template <typename T>
+static int launch_prolong(bool half, mgx_level *src, mgx_level *dst, const MgxTransferPlan *t) {
+  const MgxGeom &gs = src->g;
+  if (t->cz_hi < t->cz_lo) return MGX_OK;
+  dim3 grid((gs.n1 + 63) / 64, (gs.n2 + 3) / 4, t->cz_hi - t->cz_lo + 1);
+  hipStream_t st = C(dst)->stream;
+  const T *s = (const T *)src->buf[src->cur];
+  T *d = (T *)dst->buf[dst->cur];
+  const int2 *rx = (const int2 *)t->d_tab, *ry = (const int2 *)(t->d_tab + t->off_y), *rz = (const int2 *)(t->d_tab + t->off_z);
+  if (half) hipLaunchKernelGGL((k_prolong<T, true>), grid, dim3(256), 0, st, s, gs, d, dst->g, rx, ry, rz, t->cz_lo);
+  else hipLaunchKernelGGL((k_prolong<T, false>), grid, dim3(256), 0, st, s, gs, d, dst->g, rx, ry, rz, t->cz_lo);
+  HIP_TRY(hipGetLastError());
+  return MGX_OK;
+}
+
 extern "C" int mgx_restrict(mgx_level *parent, mgx_level *child, int method) {
   TRY(check_pair("mgx_restrict", parent, child, method));
   if (!parent->defined) return fail(MGX_ESTATE, "mgx_restrict: parent level %d was released", parent->layer);
   TRY(set_device(C(child)));
-  const MgxGeom &gp = parent->g, &gc = child->g;
-  std::vector<int> mx(gc.n1 + 2, 0), my(gc.n2 + 2, 0), mz(gc.n3g + 2, 0);
-  for (int cz = 1; cz <= gc.n3g; ++cz) mz[cz] = g2g(gc.n3g, cz, gp.n3g);            // t_mg_interp.f90:153,244
-  if (method == MGX_INTERP_HALF) {                                                   // :247-252
-    for (int cx = 1; cx <= gc.n1; ++cx) mx[cx] = g2g(gc.n1, cx, gp.n1);
-    for (int cy = 1; cy <= gc.n2; ++cy) my[cy] = g2g(gc.n2, cy, gp.n2);
-  } else {                                                                           // :156-161, last writer wins
-    for (int x = 2; x <= gp.n1; x += 2) mx[g2g(gp.n1, x, gc.n1)] = x;
-    for (int y = 2; y <= gp.n2; y += 2) my[g2g(gp.n2, y, gc.n2)] = y;
-  }
-  TRY(check_z_reach("mgx_restrict", mz, parent, child));
-  DevTable tx, ty, tz;
-  hipStream_t st = C(child)->stream;
-  TRY(upload_table(mx, tx, st)); TRY(upload_table(my, ty, st)); TRY(upload_table(mz, tz, st));
+  MgxTransferPlan *t = nullptr;
+  TRY(transfer_plan("mgx_restrict", true, parent, child, method, &t));
+  TRY(materialize(parent));
+  TRY(materialize(child));            // the full operator can leave child cells unwritten (odd sizes): they stay zero
   const bool half = method == MGX_INTERP_HALF;
-  TRY(child->elem == 4 ? launch_transfer<float>(true, half, parent, child, tx.d, ty.d, tz.d)
-                       : launch_transfer<double>(true, half, parent, child, tx.d, ty.d, tz.d));
+  TRY(child->elem == 4 ? launch_restrict<float>(half, parent, child, t) : launch_restrict<double>(half, parent, child, t));
   child->defined = true;
   TRY(child->elem == 4 ? do_setup<float>(child, 0) : do_setup<double>(child, 0));
-  HIP_TRY(hipStreamSynchronize(st));     // tables are freed on return
   return MGX_OK;
 }
 
@@ -654,21 +740,17 @@ extern "C" int mgx_prolong(mgx_level *child, mgx_level *parent, int method) {
   TRY(check_pair("mgx_prolong", child, parent, method));
   if (!child->defined) return fail(MGX_ESTATE, "mgx_prolong: child level %d was released", child->layer);
   TRY(set_device(C(parent)));
-  const MgxGeom &gp = parent->g, &gc = child->g;
-  std::vector<int> mx(gp.n1 + 2, 0), my(gp.n2 + 2, 0), mz(gp.n3g + 2, 0);
-  for (int px = 1; px <= gp.n1; ++px) mx[px] = g2g(gp.n1, px, gc.n1);               // t_mg_interp.f90:334,426
-  for (int py = 1; py <= gp.n2; ++py) my[py] = g2g(gp.n2, py, gc.n2);               // :330,422
-  for (int pz = 1; pz <= gp.n3g; ++pz) mz[pz] = g2g(gp.n3g, pz, gc.n3g);            // :326,418
-  TRY(check_z_reach("mgx_prolong", mz, child, parent));
-  DevTable tx, ty, tz;
-  hipStream_t st = C(parent)->stream;
-  TRY(upload_table(mx, tx, st)); TRY(upload_table(my, ty, st)); TRY(upload_table(mz, tz, st));
+  MgxTransferPlan *t = nullptr;
+  TRY(transfer_plan("mgx_prolong", false, child, parent, method, &t));
+  TRY(materialize(child));
+  // every interior cell of the parent is written (g2g maps onto 1..n) and grid_setup then writes every ghost:
+  // a pending zero fill of an undivided parent is void.  A slab keeps its halo planes, so it is filled first.
+  if (parent->g.n3 == parent->g.n3g) parent->zero_pending = false;
+  else TRY(materialize(parent));
   const bool half = method == MGX_INTERP_HALF;
-  TRY(parent->elem == 4 ? launch_transfer<float>(false, half, child, parent, tx.d, ty.d, tz.d)
-                        : launch_transfer<double>(false, half, child, parent, tx.d, ty.d, tz.d));
+  TRY(parent->elem == 4 ? launch_prolong<float>(half, child, parent, t) : launch_prolong<double>(half, child, parent, t));
   parent->defined = true;
   TRY(parent->elem == 4 ? do_setup<float>(parent, 0) : do_setup<double>(parent, 0));
-  HIP_TRY(hipStreamSynchronize(st));
   return MGX_OK;
 }
 
@@ -676,6 +758,7 @@ extern "C" int mgx_prolong(mgx_level *child, mgx_level *parent, int method) {
 // host <-> device
 
 static int copy_field(mgx_level *lv, void *host, bool to_device) {
+  TRY(materialize(lv));
   const MgxGeom &g = lv->g;
   const size_t es = lv->elem;
   char *dev = (char *)lv->buf[lv->cur] + (size_t)(g.idx(0, 0, 0)) * es;
@@ -708,6 +791,8 @@ extern "C" int mgx_level_plane_ptr(mgx_level *lv, int32_t z, int32_t count, void
   if (!lv || !ptr || !bytes) return fail(MGX_EINVAL, "mgx_level_plane_ptr: NULL argument");
   if (count < 1 || z < -1 || z + count - 1 > lv->g.n3 + 2)
     return fail(MGX_EINVAL, "mgx_level_plane_ptr: planes [%d,%d] outside [-1,%d]", z, z + count - 1, lv->g.n3 + 2);
+  TRY(set_device(C(lv)));
+  TRY(materialize(lv));
   // a plane = rows y = 0..n2+1, each from its x = 0 ghost to the end of the pitch
   *ptr = (char *)lv->buf[lv->cur] + (size_t)lv->g.idx(0, 0, z) * lv->elem;
   *bytes = (size_t)lv->g.pz * count * lv->elem;

@@ -384,6 +384,34 @@ __device__ inline T mgx_stencil_prolong(const T *__restrict__ V, const long long
   return vt;
 }
 
+// Prolongation, child-centred.  Every parent cell takes the stencil value around child cell
+// (g2g(px), g2g(py), g2g(pz)) (t_mg_interp.f90:326-374, :418-456); g2g is monotone, so the parent cells fed by
+// one child cell form a box [xlo,xhi] x [ylo,yhi] x [zlo,zhi] (2 x 2 x 2 cells when a dimension was halved).
+// One thread evaluates the stencil once per child cell and stores it to that box: an eighth of the loads and
+// arithmetic of a parent-centred loop, same values.  Range tables hold lo and hi per child index (lo > hi: no
+// parent cell maps there); z tables are indexed by GLOBAL child plane and hold GLOBAL parent planes.
+template <typename T, bool HALF>
+__global__ __launch_bounds__(256) void k_prolong(const T *__restrict__ src, const MgxGeom gs, T *__restrict__ dst,
+                                                 const MgxGeom gd, const int2 *__restrict__ rx,
+                                                 const int2 *__restrict__ ry, const int2 *__restrict__ rz,
+                                                 const int czg0) {
+  const int cx = blockIdx.x * 64 + (threadIdx.x & 63) + 1;
+  const int cy = blockIdx.y * 4 + (threadIdx.x >> 6) + 1;
+  const int czg = czg0 + blockIdx.z;                    // global child plane
+  if (cx > gs.n1 || cy > gs.n2) return;
+  const int2 xr = rx[cx], yr = ry[cy];
+  int2 zr = rz[czg];
+  zr.x = max(zr.x, gd.z0 + 1) - gd.z0;                  // parent planes of this slab, local
+  zr.y = min(zr.y, gd.z0 + gd.n3) - gd.z0;
+  if (xr.x > xr.y || yr.x > yr.y || zr.x > zr.y) return;
+  const T v = mgx_stencil_prolong<T, HALF>(src, gs.idx(cx, cy, czg - gs.z0), gs.px, gs.pz);
+  for (int pz = zr.x; pz <= zr.y; ++pz)
+    for (int py = yr.x; py <= yr.y; ++py) {
+      T *row = dst + gd.idx(0, py, pz);
+      for (int px = xr.x; px <= xr.y; ++px) row[px] = v;
+    }
+}
+
 // generic transfer: `dst` cell (dx,dy,dz) := stencil of `src` around (mx[dx], my[dy], mz[dz]);
 // RESTRICT selects the accumulation order.  Block = 64 x * 4 y, one z plane per blockIdx.z.
 template <typename T, bool HALF, bool RESTRICT>

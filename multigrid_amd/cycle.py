@@ -154,8 +154,9 @@ class Solver:
             self.record(grid, 0, tol, new_sum)
             self.say(f" itt {grid.itt - old_itt:6d} {float(tol):10.7f} {float(new_sum * nr):10.7f} {grid.err:10.7f}")
 
-    def _leg(self, grid):
-        """steps × gs_step between two (print-only) sums: m_gs_CDS.F90:237-248 / :268-278"""
+    def _leg(self, grid, want_sum: bool = False):
+        """steps × gs_step between two (print-only) sums: m_gs_CDS.F90:237-248 / :268-278.  Returns the grid_sum
+        after the last step when asked (the caller's own grid_sum would read the same field)."""
         t = self.t
         if self.print_sums:
             nr = t(1) / t(self.count(grid))
@@ -164,11 +165,12 @@ class Solver:
             tol = t(abs(t(old_sum - new_sum)) * nr)
             self.record(grid, 1, tol, new_sum)
             self.say(f"      {'  ' * grid.layer}{grid.steps:6d} {float(tol):10.7f} {float(new_sum * nr):10.7f}")
-        else:
-            self.gs_steps(grid, grid.steps, False)
+            return new_sum
+        return self.gs_steps(grid, grid.steps, want_sum)
 
     def gs_V(self, pg, cg):
-        """m_gs_CDS.F90:220-294"""
+        """m_gs_CDS.F90:220-294.  Returns grid_sum(pg) as it stands when the cycle ends (the sum the caller
+        evaluates next, m_gs_CDS.F90:149, comes out of the last sweep's own reduction), or None."""
         grid = pg
         while grid.layer != cg.layer:
             if not grid.child.enabled:
@@ -179,9 +181,10 @@ class Solver:
             self.hold_back(grid)
             grid = grid.child
         while True:
-            self._leg(grid)
-            if grid.layer == pg.layer:
-                break
+            last = grid.layer == pg.layer
+            s_end = self._leg(grid, want_sum=last)
+            if last:
+                return s_end if grid.steps > 0 else None
             if grid.parent is not None:
                 self.bring_back(grid.parent)
                 lib.prolong(grid.dev, grid.parent.dev, grid.PRO_method)
@@ -216,8 +219,9 @@ class Solver:
             pg_tol = self.tolerance(pg)
             itol = t(pg_tol + t(1))
             while itol > pg_tol:
-                self.gs_V(pg, cg)
-                new_sum = self.grid_sum(pg)
+                new_sum = self.gs_V(pg, cg)
+                if new_sum is None:
+                    new_sum = self.grid_sum(pg)
                 itol = t(abs(t(old_sum - new_sum)) * nr)
                 old_sum = new_sum
                 self.record(pg, 2, itol, new_sum)

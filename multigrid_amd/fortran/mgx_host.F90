@@ -276,8 +276,11 @@ contains
   end subroutine grid_solve
 
   ! `steps` sweeps of one level between two print-only sums (m_gs_CDS.F90:237-248, :268-278)
-  subroutine leg(grid)
+  ! `s_end` = grid_sum after the last step, when `want_sum` asks for it (or the print-only sums are on)
+  subroutine leg(grid, want_sum, s_end)
     type(host_grid), intent(inout) :: grid
+    logical, intent(in) :: want_sum
+    real(grid_p), intent(out) :: s_end
     real(grid_p) :: nr, old_sum, new_sum, tol
     if ( print_sums ) then
        nr = 1._grid_p / real(grid_non_constant_elem(grid), grid_p)
@@ -286,25 +289,39 @@ contains
        tol = abs(old_sum - new_sum) * nr
        call record(grid, 1, tol, new_sum)
     else
-       call gs_steps(grid, grid%steps, .false., new_sum)
+       call gs_steps(grid, grid%steps, want_sum, new_sum)
     end if
+    s_end = new_sum
   end subroutine leg
 
-  subroutine gs_V(pg, cg)                           ! m_gs_CDS.F90:220-294
+  ! m_gs_CDS.F90:220-294.  `end_sum` = grid_sum(pg) as it stands when the cycle ends: the sum the caller
+  ! evaluates next (m_gs_CDS.F90:149) comes out of the last sweep's own reduction.
+  subroutine gs_V(pg, cg, end_sum, have_sum)
     type(host_grid), intent(inout), target :: pg, cg
+    real(grid_p), intent(out) :: end_sum
+    logical, intent(out) :: have_sum
     type(host_grid), pointer :: grid
+    real(grid_p) :: s
+    logical :: last
+    end_sum = 0._grid_p
+    have_sum = .false.
     grid => pg
     do while ( grid%layer /= cg%layer )
        if ( .not. grid%child%enabled ) exit
-       call leg(grid)
+       call leg(grid, .false., s)
        call grid_bring_back(grid%child)
        call mgx_check(mgx_restrict(grid%h, grid%child%h, int(grid%RES_method, c_int)))
        call grid_hold_back(grid)
        grid => grid%child
     end do
     do
-       call leg(grid)
-       if ( grid%layer == pg%layer ) exit
+       last = grid%layer == pg%layer
+       call leg(grid, last, s)
+       if ( last ) then
+          have_sum = grid%steps > 0
+          end_sum = s
+          exit
+       end if
        if ( associated(grid%parent) ) then
           call grid_bring_back(grid%parent)
           call mgx_check(mgx_prolong(grid%h, grid%parent%h, int(grid%PRO_method, c_int)))
@@ -320,7 +337,7 @@ contains
     type(host_grid), intent(inout), target :: top
     type(host_grid), pointer :: pg, cg
     real(grid_p) :: tol, itol, nr, old_sum, new_sum, pg_tol, top_tol, outer
-    logical :: on_inner
+    logical :: on_inner, have
     integer :: old_itt
     if ( .not. associated(top%child) ) stop 'gs_w needs at least two levels'
     pg => top
@@ -346,8 +363,8 @@ contains
        pg_tol = grid_tolerance(pg)
        itol = pg_tol + 1._grid_p
        do while ( itol > pg_tol )
-          call gs_V(pg, cg)
-          new_sum = grid_sum(pg)
+          call gs_V(pg, cg, new_sum, have)
+          if ( .not. have ) new_sum = grid_sum(pg)
           itol = abs(old_sum - new_sum) * nr
           old_sum = new_sum
           call record(pg, 2, itol, new_sum)
