@@ -710,13 +710,14 @@ template <typename T>
 static int launch_prolong(bool half, mgx_level *src, mgx_level *dst, const MgxTransferPlan *t) {
   const MgxGeom &gs = src->g;
   if (t->cz_hi < t->cz_lo) return MGX_OK;
-  dim3 grid((gs.n1 + 63) / 64, (gs.n2 + 3) / 4, t->cz_hi - t->cz_lo + 1);
+  constexpr int ZCH = 16;        // child planes one thread marches
+  dim3 grid((gs.n1 + 63) / 64, (gs.n2 + 3) / 4, (t->cz_hi - t->cz_lo + ZCH) / ZCH);
   hipStream_t st = C(dst)->stream;
   const T *s = (const T *)src->buf[src->cur];
   T *d = (T *)dst->buf[dst->cur];
   const int2 *rx = (const int2 *)t->d_tab, *ry = (const int2 *)(t->d_tab + t->off_y), *rz = (const int2 *)(t->d_tab + t->off_z);
-  if (half) hipLaunchKernelGGL((k_prolong<T, true>), grid, dim3(256), 0, st, s, gs, d, dst->g, rx, ry, rz, t->cz_lo);
-  else hipLaunchKernelGGL((k_prolong<T, false>), grid, dim3(256), 0, st, s, gs, d, dst->g, rx, ry, rz, t->cz_lo);
+  if (half) hipLaunchKernelGGL((k_prolong<T, true, ZCH>), grid, dim3(256), 0, st, s, gs, d, dst->g, rx, ry, rz, t->cz_lo, t->cz_hi);
+  else hipLaunchKernelGGL((k_prolong<T, false, ZCH>), grid, dim3(256), 0, st, s, gs, d, dst->g, rx, ry, rz, t->cz_lo, t->cz_hi);
   HIP_TRY(hipGetLastError());
   return MGX_OK;
 }

@@ -25,9 +25,14 @@
 // Boxes (t_mg.f90:634-710).  A tile no box reaches runs a body without any box logic (weights
 // a(dir)/sum, precomputed on the host with the reference's arithmetic).  Other tiles use bit sets
 // over the (at most 32) boxes: in_box(b,x,y,z) = X_b(x) & Y_b(y) & Z_b(z); the X and Y sets of a lane's
-// pairs are constant along z and live in registers, the Z sets of planes k-1, k, k+1 are made by
-// wave 4 with a ballot per step.  "any constant box" = set & constant-mask, "first box" = lowest
-// set bit, exactly the reference's scans.
+// pairs are constant along z (per-block LDS tables), the Z sets of planes k-1, k, k+1 are made by the halo
+// wave with a ballot per step.  "any constant box" = set & constant-mask, "first box" = lowest set bit,
+// exactly the reference's scans.  The scans are not run per cell and step: their outcome for a cell is a
+// small code (is it constant; which of its six neighbours lie in a box with rho != 1, i.e. which entry of a
+// per-block table of weight sextuples applies) that depends on z only through the Z sets of four planes,
+// so every lane keeps the codes of its cells and recomputes them (off the hot path) only when those
+// Z sets change, i.e. at the z faces of boxes.  Cells that see two different boxes with rho != 1 are
+// flagged and evaluate the reference's six divisions.
 #pragma once
 
 #include "mgx_kernels.hpp"
@@ -55,58 +60,111 @@ template <> struct MgxVec2<float> { typedef float2 type; };
 #define MGX_MAX_FUSED_BOXES 32
 
 template <typename T>
-struct MgxBoxLds {           // per-block copy of what the box body needs
+struct MgxBoxLds {           // per-block copy of what the box logic needs
   unsigned zsets[2][4];      // [step parity][plane k-1, k, k+1, unused]
   T rho[MGX_MAX_FUSED_BOXES + 1];   // rho of box b; slot 32 = 1 (no box)
-  T win[MGX_MAX_FUSED_BOXES + 1][3]; // weights of a cell whose six neighbours all have box b first (slot 32: none)
+  // weights of a cell whose neighbours x-,x+,y-,y+,z-,z+ (bit i of m) have table box t (the first or second box
+  // with rho != 1) as their first box, the others rho = 1: made once per block with the reference's arithmetic
+  // (rho*a, sequential sum, six divisions, m_gs_CDS.F90:729-735); entry [0][0] is the box-free cell
+  T wtab[2][64][6];
+  uint4 xq[64 + 2];          // X sets of positions xs-1 .. xs+2 around staged pair column pc
+  uint4 yq[64];              // Y sets of rows y-1, y, y+1 around staged row r (rows past the tile: empty)
 };
 
-// new value of one cell in a tile that boxes reach.  sets: boxes containing the cell (c) and its six
-// neighbours; cmask: constant boxes; rmask: boxes with rho != 1.
+#define MGX_CODE_CONST 128u     // the cell lies in a constant box: val returns V itself (m_gs_CDS.F90:726-727)
+#define MGX_CODE_GENERAL 256u   // neighbours in two boxes with rho != 1, or in one without a table
+struct MgxCodes { unsigned c[3]; };   // per pair: low half = black cell of plane k, high half = red cell of plane k-1
+
+// code of one cell from the sets of its own position and of its neighbours' positions
+__device__ inline unsigned mgx_cell_code(const unsigned X0, const unsigned Xm, const unsigned Xp, const uint4 ys,
+                                         const unsigned zl, const unsigned zc, const unsigned zh, const unsigned cmask,
+                                         const unsigned rmask, const unsigned tb0, const unsigned tb1) {
+  const unsigned c00 = ys.y & zc;
+  const unsigned sxm = Xm & c00, sxp = Xp & c00, sym = X0 & ys.x & zc, syp = X0 & ys.z & zc, szm = X0 & ys.y & zl,
+                 szp = X0 & ys.y & zh;
+  // first containing box decides rho (t_mg.f90:670-687); lowest set bit = first box; keep it only if rho != 1
+  const unsigned rxm = sxm & (0u - sxm) & rmask, rxp = sxp & (0u - sxp) & rmask, rym = sym & (0u - sym) & rmask,
+                 ryp = syp & (0u - syp) & rmask, rzm = szm & (0u - szm) & rmask, rzp = szp & (0u - szp) & rmask;
+  const unsigned R = rxm | rxp | rym | ryp | rzm | rzp;
+  const bool general = (R & (R - 1u)) != 0u || (R & ~(tb0 | tb1)) != 0u;
+  const unsigned m = (rxm ? 1u : 0u) | (rxp ? 2u : 0u) | (rym ? 4u : 0u) | (ryp ? 8u : 0u) | (rzm ? 16u : 0u) |
+                     (rzp ? 32u : 0u);
+  return (general ? MGX_CODE_GENERAL : (((R & tb1) ? 64u : 0u) | m)) | ((X0 & c00 & cmask) ? MGX_CODE_CONST : 0u);
+}
+
+// codes of the (up to three) pairs of a lane for one step: black cells on the plane with Z sets (zm, z0, zp) around
+// it, red cells one plane below (zmm, zm, z0).  qsel bit j = position of the cell in pair j.
 template <typename T>
-__device__ inline T mgx_cell_new_sets(const T vc, const T vxm, const T vxp, const T vym, const T vyp, const T vzm,
-                                      const T vzp, const unsigned sc, const unsigned sxm, const unsigned sxp,
-                                      const unsigned sym, const unsigned syp, const unsigned szm, const unsigned szp,
-                                      const unsigned cmask, const unsigned rmask, const MgxBoxLds<T> *__restrict__ bl,
-                                      const MgxSweepParams<T> &p) {
-  const T *__restrict__ rho = bl->rho;
-  T avg;
-  if (sc & cmask) {
-    avg = vc;                                            // val returns V itself (m_gs_CDS.F90:726-727)
-  } else {
-    // first containing box decides rho (t_mg.f90:670-687); lowest set bit = first box
-    const unsigned fx = sxm & (0u - sxm), fxp = sxp & (0u - sxp), fy = sym & (0u - sym), fyp = syp & (0u - syp),
-                   fz = szm & (0u - szm), fzp = szp & (0u - szp);
-    if (((fx | fxp | fy | fyp | fz | fzp) & rmask) == 0) {
-      avg = mgx_avg_uniform<T>(vxm, vxp, vym, vyp, vzm, vzp, p.w);
-    } else if (fx == fxp && fx == fy && fx == fyp && fx == fz && fx == fzp) {
-      // all six neighbours have the same first box: its weights were made once per block with the very
-      // arithmetic of the general branch below (rho*a, sequential sum, six divisions)
-      const T *w = bl->win[__ffs((int)fx) - 1];
-      avg = vxm * w[0] + vxp * w[0];
-      avg = avg + vym * w[1];
-      avg = avg + vyp * w[1];
-      avg = avg + vzm * w[2];
-      avg = avg + vzp * w[2];
-    } else {
-      T r[6];
-      r[0] = rho[sxm ? __ffs((int)sxm) - 1 : 32] * p.a[0];
-      r[1] = rho[sxp ? __ffs((int)sxp) - 1 : 32] * p.a[0];
-      r[2] = rho[sym ? __ffs((int)sym) - 1 : 32] * p.a[1];
-      r[3] = rho[syp ? __ffs((int)syp) - 1 : 32] * p.a[1];
-      r[4] = rho[szm ? __ffs((int)szm) - 1 : 32] * p.a[2];
-      r[5] = rho[szp ? __ffs((int)szp) - 1 : 32] * p.a[2];
-      T s = r[0];
-      s = s + r[1]; s = s + r[2]; s = s + r[3]; s = s + r[4]; s = s + r[5];
+__device__ inline MgxCodes mgx_box_codes(const MgxBoxLds<T> *bl, const int pcs, const int r0, const int r1,
+                                               const int r2, const unsigned qsel, const unsigned zmm, const unsigned zm,
+                                               const unsigned z0, const unsigned zp, const unsigned cmask,
+                                               const unsigned rmask, const unsigned tb0, const unsigned tb1) {
+  MgxCodes out;
+  const uint4 xs4 = bl->xq[pcs];
 #pragma unroll
-      for (int i = 0; i < 6; ++i) r[i] = r[i] / s;
-      avg = vxm * r[0] + vxp * r[1];
-      avg = avg + vym * r[2];
-      avg = avg + vyp * r[3];
-      avg = avg + vzm * r[4];
-      avg = avg + vzp * r[5];
+  for (int j = 0; j < 3; ++j) {
+    const uint4 ys = bl->yq[j == 0 ? r0 : j == 1 ? r1 : r2];
+    const bool q = ((qsel >> j) & 1u) != 0u;
+    const unsigned X0 = q ? xs4.z : xs4.y, Xm = q ? xs4.y : xs4.x, Xp = q ? xs4.w : xs4.z;
+    out.c[j] = mgx_cell_code(X0, Xm, Xp, ys, zm, z0, zp, cmask, rmask, tb0, tb1) |
+               (mgx_cell_code(X0, Xm, Xp, ys, zmm, zm, z0, cmask, rmask, tb0, tb1) << 16);
+  }
+  return out;
+}
+
+// weighted average of a flagged cell: the reference's arithmetic with the rho of every neighbour looked up
+template <typename T>
+__device__ inline T mgx_general_avg(const MgxBoxLds<T> *bl, const T vxm, const T vxp, const T vym, const T vyp,
+                                          const T vzm, const T vzp, const int pcs, const int r, const int q,
+                                          const unsigned zl, const unsigned zc, const unsigned zh, const T a0, const T a1,
+                                          const T a2) {
+  const uint4 xs4 = bl->xq[pcs], ys = bl->yq[r];
+  const unsigned X0 = q ? xs4.z : xs4.y, Xm = q ? xs4.y : xs4.x, Xp = q ? xs4.w : xs4.z;
+  const unsigned c00 = ys.y & zc;
+  const unsigned sxm = Xm & c00, sxp = Xp & c00, sym = X0 & ys.x & zc, syp = X0 & ys.z & zc, szm = X0 & ys.y & zl,
+                 szp = X0 & ys.y & zh;
+  const T *rho = bl->rho;
+  T r6[6];
+  r6[0] = rho[sxm ? __ffs((int)sxm) - 1 : 32] * a0;
+  r6[1] = rho[sxp ? __ffs((int)sxp) - 1 : 32] * a0;
+  r6[2] = rho[sym ? __ffs((int)sym) - 1 : 32] * a1;
+  r6[3] = rho[syp ? __ffs((int)syp) - 1 : 32] * a1;
+  r6[4] = rho[szm ? __ffs((int)szm) - 1 : 32] * a2;
+  r6[5] = rho[szp ? __ffs((int)szp) - 1 : 32] * a2;
+  T s = r6[0];
+  s = s + r6[1]; s = s + r6[2]; s = s + r6[3]; s = s + r6[4]; s = s + r6[5];
+#pragma unroll
+  for (int i = 0; i < 6; ++i) r6[i] = r6[i] / s;
+  T avg = vxm * r6[0] + vxp * r6[1];
+  avg = avg + vym * r6[2];
+  avg = avg + vyp * r6[3];
+  avg = avg + vzm * r6[4];
+  avg = avg + vzp * r6[5];
+  return avg;
+}
+
+// new value of a cell from its code (a tile that boxes reach).  All lanes of the wave call it together.
+template <typename T, int BOXES>
+__device__ inline T mgx_cell_from_code(const unsigned code, const T vc, const T vxm, const T vxp, const T vym, const T vyp,
+                                       const T vzm, const T vzp, const MgxBoxLds<T> *__restrict__ bl, const int pcs,
+                                       const int r, const int q, const unsigned zl, const unsigned zc, const unsigned zh,
+                                       const MgxSweepParams<T> &p) {
+  T avg;
+  if (BOXES == 1) {            // only boxes with rho = 1 reach this tile: "is the cell constant" is all that matters
+    avg = mgx_avg_uniform<T>(vxm, vxp, vym, vyp, vzm, vzp, p.w);
+  } else {
+    const T *__restrict__ w = &bl->wtab[0][0][0] + (code & 127u) * 6u;
+    avg = vxm * w[0] + vxp * w[1];
+    avg = avg + vym * w[2];
+    avg = avg + vyp * w[3];
+    avg = avg + vzm * w[4];
+    avg = avg + vzp * w[5];
+    if (__builtin_expect(__any((code & MGX_CODE_GENERAL) != 0u), 0)) {
+      const T gavg = mgx_general_avg<T>(bl, vxm, vxp, vym, vyp, vzm, vzp, pcs, r, q, zl, zc, zh, p.a[0], p.a[1], p.a[2]);
+      avg = (code & MGX_CODE_GENERAL) ? gavg : avg;
     }
   }
+  avg = (code & MGX_CODE_CONST) ? vc : avg;
   return p.s1 * vc + p.s2 * avg;
 }
 
@@ -163,7 +221,9 @@ __device__ __forceinline__ void mgx_fused_body(const T *__restrict__ src, T *__r
   int li[R], fl[R];
   unsigned gob[R];                       // byte offset of the pair inside a plane
   bool st[R];
-  unsigned mx[R][4], my[R][3];           // BOXES: boxes whose x range holds xs-1..xs+2 / y range holds y-1..y+1
+  int rr[3] = {0, 0, 0};                 // staged row of pair j
+  int pcs = 0;                           // staged pair column (the same for every pair of a lane)
+  static_assert(R <= 3, "a lane keeps the box codes of at most three pairs");
 #pragma unroll
   for (int j = 0; j < R; ++j) {
     int r, pc;
@@ -191,21 +251,10 @@ __device__ __forceinline__ void mgx_fused_body(const T *__restrict__ src, T *__r
     fl[j] = f;
     gob[j] = (unsigned)((ld ? g.front + (long long)(xs - 1) + (long long)g.px * y : g.front) * (long long)sizeof(T));
     st[j] = (f & MGX_F_STORE) != 0;
-    if (BOXES) {
-#pragma unroll
-      for (int d = 0; d < 4; ++d) mx[j][d] = 0u;
-#pragma unroll
-      for (int d = 0; d < 3; ++d) my[j][d] = 0u;
-      for (int b = 0; b < nb; ++b) {
-        const int l0 = bx[b].lo[0], h0 = bx[b].hi[0], l1 = bx[b].lo[1], h1 = bx[b].hi[1];
-#pragma unroll
-        for (int d = 0; d < 4; ++d) mx[j][d] |= (l0 <= xs - 1 + d && xs - 1 + d <= h0) ? (1u << b) : 0u;
-#pragma unroll
-        for (int d = 0; d < 3; ++d) my[j][d] |= (l1 <= y - 1 + d && y - 1 + d <= h1) ? (1u << b) : 0u;
-      }
-    }
+    rr[j] = r;
+    pcs = pc;
   }
-  unsigned cmask = 0u, rmask = 0u;
+  unsigned cmask = 0u, rmask = 0u, tb0 = 0u, tb1 = 0u;
   int blo2 = 1, bhi2 = 0;                // z range of "my" box (halo wave: lane = box)
   if (BOXES) {
     for (int b = 0; b < nb; ++b) {
@@ -213,15 +262,32 @@ __device__ __forceinline__ void mgx_fused_body(const T *__restrict__ src, T *__r
       rmask |= bx[b].rho_is_one ? 0u : (1u << b);
     }
     if (HALO && lane < nb) { blo2 = bx[lane].lo[2]; bhi2 = bx[lane].hi[2]; }
-    if (!HALO && threadIdx.x <= MGX_MAX_FUSED_BOXES) {
-      const T rb = threadIdx.x < nb ? (T)bx[threadIdx.x].rho : (T)1;
-      bl->rho[threadIdx.x] = rb;
-      T r[6] = {rb * p.a[0], rb * p.a[0], rb * p.a[1], rb * p.a[1], rb * p.a[2], rb * p.a[2]};
+    tb0 = rmask & (0u - rmask);
+    tb1 = (rmask ^ tb0) & (0u - (rmask ^ tb0));
+    if (!HALO && threadIdx.x <= MGX_MAX_FUSED_BOXES) bl->rho[threadIdx.x] = threadIdx.x < nb ? (T)bx[threadIdx.x].rho : (T)1;
+    if (!HALO && threadIdx.x < LP + 64) {          // waves 0 to 2 (row waves: NW >= 4); rows past LR get empty sets
+      const bool isx = threadIdx.x < LP;
+      const int pos = isx ? tx0 - 2 + 2 * (int)threadIdx.x - 1 : ty0 - 2 + ((int)threadIdx.x - LP) - 1;   // first position
+      unsigned q4[4] = {0u, 0u, 0u, 0u};
+      for (int b = 0; b < nb && (isx || (int)threadIdx.x - LP < LR); ++b) {
+        const int lo = isx ? bx[b].lo[0] : bx[b].lo[1], hi = isx ? bx[b].hi[0] : bx[b].hi[1];
+#pragma unroll
+        for (int d = 0; d < 4; ++d) q4[d] |= (lo <= pos + d && pos + d <= hi) ? (1u << b) : 0u;
+      }
+      const uint4 v4 = make_uint4(q4[0], q4[1], q4[2], isx ? q4[3] : 0u);
+      if (isx) bl->xq[threadIdx.x] = v4; else bl->yq[threadIdx.x - LP] = v4;
+    }
+    if (BOXES == 2 && !HALO && threadIdx.x >= 128 && threadIdx.x < 256) {     // waves 2 and 3
+      const int t = (threadIdx.x - 128) >> 6, m = threadIdx.x & 63;
+      const unsigned tb = t ? tb1 : tb0;
+      const T rb = tb ? (T)bx[__ffs((int)tb) - 1].rho : (T)1;
+      T r[6];
+#pragma unroll
+      for (int i = 0; i < 6; ++i) r[i] = (((m >> i) & 1) ? rb : (T)1) * p.a[i >> 1];
       T s = r[0];
       s = s + r[1]; s = s + r[2]; s = s + r[3]; s = s + r[4]; s = s + r[5];
-      bl->win[threadIdx.x][0] = r[0] / s;
-      bl->win[threadIdx.x][1] = r[2] / s;
-      bl->win[threadIdx.x][2] = r[4] / s;
+#pragma unroll
+      for (int i = 0; i < 6; ++i) bl->wtab[t][m][i] = r[i] / s;
     }
   }
   // Z sets for planes zz-1, zz, zz+1 (global), written by the halo wave into parity slot `par`
@@ -271,6 +337,26 @@ __device__ __forceinline__ void mgx_fused_body(const T *__restrict__ src, T *__r
   MGX_STAGE(sk, 1, 0)              // set 1 = plane zc0-1 = plane k of the first step (unroll position 0)
   make_zsets(zc0 - 1 + g.z0, (zc0 - 1) & 1);
   MGX_SYNC();
+  unsigned xyany = 0u;                   // boxes that can contain a cell of this lane's pairs, or a neighbour of one
+  unsigned codes[2][3];                  // box codes of the pairs, per step parity; valid for the Z sets in `key`
+  unsigned key[2][4];
+  bool kvalid[2] = {false, false};
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 3; ++j) codes[i][j] = 0u;
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int d = 0; d < 4; ++d) key[i][d] = 0u;
+  if (BOXES) {
+    const uint4 xs4 = bl->xq[pcs];
+#pragma unroll
+    for (int j = 0; j < R; ++j) {
+      const uint4 ys4 = bl->yq[rr[j]];
+      xyany |= (xs4.x | xs4.y | xs4.z | xs4.w) & (ys4.x | ys4.y | ys4.z);
+    }
+  }
 
   T err = (T)0;                    // max |vv - V|, squared once at the end (rounding is monotone: same bits)
   u64 slo = 0, shi = 0;
@@ -305,7 +391,25 @@ __device__ __forceinline__ void mgx_fused_body(const T *__restrict__ src, T *__r
       const int sm = sk == 0 ? 2 : sk - 1, sp = sk == 2 ? 0 : sk + 1;
       MGX_FETCH(min(k + 1 + D, zc1 + 2), SF)
       unsigned zm = 0u, z0s = 0u, zp = 0u;
-      if (BOXES) { zm = bl->zsets[k & 1][0]; z0s = bl->zsets[k & 1][1]; zp = bl->zsets[k & 1][2]; }
+      bool boxy = false;           // can a box touch this wave's pairs on planes k-2 .. k+1?
+      if (BOXES) {
+        zm = bl->zsets[k & 1][0]; z0s = bl->zsets[k & 1][1]; zp = bl->zsets[k & 1][2];
+        boxy = __any((xyany & (zmm | zm | z0s | zp)) != 0u);
+        if (boxy) {                // the codes of this step parity stand until one of the four Z sets changes
+          const bool stale = !kvalid[u & 1] || key[u & 1][0] != zmm || key[u & 1][1] != zm || key[u & 1][2] != z0s ||
+                             key[u & 1][3] != zp;
+          if (__builtin_expect(__any(stale), 0)) {
+            unsigned qsel = 0u;
+#pragma unroll
+            for (int j = 0; j < R; ++j) qsel |= (unsigned)MGX_Q(u, j) << j;
+            const MgxCodes cd = mgx_box_codes<T>(bl, pcs, rr[0], rr[1], rr[2], qsel, zmm, zm, z0s, zp, cmask, rmask, tb0, tb1);
+#pragma unroll
+            for (int j = 0; j < 3; ++j) codes[u & 1][j] = cd.c[j];
+            key[u & 1][0] = zmm; key[u & 1][1] = zm; key[u & 1][2] = z0s; key[u & 1][3] = zp;
+            kvalid[u & 1] = true;
+          }
+        }
+      }
 
       // ---------------- black cells of plane k ----------------
       // (each phase: all LDS reads first, then all arithmetic, then the writes and the reductions, so that
@@ -327,16 +431,9 @@ __device__ __forceinline__ void mgx_fused_body(const T *__restrict__ src, T *__r
           const T vc = MGX_BLK(SC, u, j), partner = MGX_RED(SC, u, j);
           const T zlo = MGX_RED(SM, u + 1, j), zhi = MGX_RED(SN, u + 1, j);   // planes k-1 and k+1 (same parity as each other)
           T vv;
-          if (BOXES == 1) {       // only boxes with rho = 1 reach this tile: "is the cell constant" is all that matters
-            const unsigned sc = (q ? mx[j][2] : mx[j][1]) & my[j][1] & z0s;
-            const T avg = (sc & cmask) ? vc : mgx_avg_uniform<T>(partner, other[j], vym[j], vyp[j], zlo, zhi, p.w);
-            vv = p.s1 * vc + p.s2 * avg;
-          } else if (BOXES == 2) {
-            const unsigned X0 = q ? mx[j][2] : mx[j][1], Xm = q ? mx[j][1] : mx[j][0], Xp = q ? mx[j][3] : mx[j][2];
-            const unsigned XY = X0 & my[j][1];
-            vv = mgx_cell_new_sets<T>(vc, q ? partner : other[j], q ? other[j] : partner, vym[j], vyp[j], zlo, zhi,
-                                      XY & z0s, Xm & my[j][1] & z0s, Xp & my[j][1] & z0s, X0 & my[j][0] & z0s,
-                                      X0 & my[j][2] & z0s, XY & zm, XY & zp, cmask, rmask, bl, p);
+          if (BOXES != 0 && boxy) {
+            vv = mgx_cell_from_code<T, BOXES>(codes[u & 1][j] & 0xffffu, vc, q ? partner : other[j], q ? other[j] : partner,
+                                              vym[j], vyp[j], zlo, zhi, bl, pcs, rr[j], q, zm, z0s, zp, p);
           } else {
             // x-1 and x+1 carry the same weight and a*w + b*w commutes exactly: no need to order them
 #ifdef MGX_ABLATE_COMPUTE
@@ -385,16 +482,9 @@ __device__ __forceinline__ void mgx_fused_body(const T *__restrict__ src, T *__r
           const T vc = MGX_RED(SM, u + 1, j), partner = MGX_BLK(SM, u + 1, j);
           const T zhi = MGX_BLK(SC, u, j);                  // new black value of plane k
           T vv;
-          if (BOXES == 1) {
-            const unsigned sc = (q ? mx[j][2] : mx[j][1]) & my[j][1] & zm;
-            const T avg = (sc & cmask) ? vc : mgx_avg_uniform<T>(partner, other[j], vym[j], vyp[j], below[j], zhi, p.w);
-            vv = p.s1 * vc + p.s2 * avg;
-          } else if (BOXES == 2) {
-            const unsigned X0 = q ? mx[j][2] : mx[j][1], Xm = q ? mx[j][1] : mx[j][0], Xp = q ? mx[j][3] : mx[j][2];
-            const unsigned XY = X0 & my[j][1];
-            vv = mgx_cell_new_sets<T>(vc, q ? partner : other[j], q ? other[j] : partner, vym[j], vyp[j], below[j], zhi,
-                                      XY & zm, Xm & my[j][1] & zm, Xp & my[j][1] & zm, X0 & my[j][0] & zm,
-                                      X0 & my[j][2] & zm, XY & zmm, XY & z0s, cmask, rmask, bl, p);
+          if (BOXES != 0 && boxy) {
+            vv = mgx_cell_from_code<T, BOXES>(codes[u & 1][j] >> 16, vc, q ? partner : other[j], q ? other[j] : partner,
+                                              vym[j], vyp[j], below[j], zhi, bl, pcs, rr[j], q, zmm, zm, z0s, p);
           } else {
 #ifdef MGX_ABLATE_COMPUTE
             vv = vc + other[j] + vym[j] + vyp[j] + below[j] + zhi + partner;

@@ -390,26 +390,97 @@ __device__ inline T mgx_stencil_prolong(const T *__restrict__ V, const long long
 // One thread evaluates the stencil once per child cell and stores it to that box: an eighth of the loads and
 // arithmetic of a parent-centred loop, same values.  Range tables hold lo and hi per child index (lo > hi: no
 // parent cell maps there); z tables are indexed by GLOBAL child plane and hold GLOBAL parent planes.
+// the prolongation stencil from three 3x3 plane patches q[(dy+1)*3 + (dx+1)], in the reference's order
+// (t_mg_interp.f90:340-374; half :432-456)
 template <typename T, bool HALF>
+__device__ inline T mgx_prolong_from_planes(const T (&zm)[9], const T (&z0)[9], const T (&zp)[9]) {
+  const T den = HALF ? (T)56 : (T)64;
+  const T f4 = (T)1 / den, f3 = (T)2 / den, f2 = (T)4 / den, f1 = (T)8 / den;
+#define Q(a, dx, dy) a[((dy) + 1) * 3 + (dx) + 1]
+  T vt = Q(z0, 0, 0) * f1;
+  vt = vt + Q(z0, -1, 0) * f2;
+  vt = vt + Q(z0, +1, 0) * f2;
+  vt = vt + Q(z0, 0, -1) * f2;
+  vt = vt + Q(z0, 0, +1) * f2;
+  vt = vt + Q(zm, 0, 0) * f2;
+  vt = vt + Q(zp, 0, 0) * f2;
+  vt = vt + Q(z0, -1, -1) * f3;
+  vt = vt + Q(z0, -1, +1) * f3;
+  vt = vt + Q(zm, -1, 0) * f3;
+  vt = vt + Q(zp, -1, 0) * f3;
+  vt = vt + Q(z0, +1, -1) * f3;
+  vt = vt + Q(z0, +1, +1) * f3;
+  vt = vt + Q(zm, +1, 0) * f3;
+  vt = vt + Q(zp, +1, 0) * f3;
+  vt = vt + Q(zm, 0, -1) * f3;
+  vt = vt + Q(zp, 0, -1) * f3;
+  vt = vt + Q(zm, 0, +1) * f3;
+  vt = vt + Q(zp, 0, +1) * f3;
+  if (!HALF) {
+    vt = vt + Q(zm, -1, -1) * f4;
+    vt = vt + Q(zp, -1, -1) * f4;
+    vt = vt + Q(zm, -1, +1) * f4;
+    vt = vt + Q(zp, -1, +1) * f4;
+    vt = vt + Q(zm, +1, -1) * f4;
+    vt = vt + Q(zp, +1, -1) * f4;
+    vt = vt + Q(zm, +1, +1) * f4;
+    vt = vt + Q(zp, +1, +1) * f4;
+  }
+#undef Q
+  return vt;
+}
+
+// One thread marches ZCH child planes of one child column (cx, cy), keeping the 3x3 patches of planes
+// cz-1, cz, cz+1 in registers (nine loads per child cell instead of 27), evaluates the stencil once per child
+// cell and stores it to the parent cells that cell feeds.
+template <typename T, bool HALF, int ZCH>
 __global__ __launch_bounds__(256) void k_prolong(const T *__restrict__ src, const MgxGeom gs, T *__restrict__ dst,
                                                  const MgxGeom gd, const int2 *__restrict__ rx,
                                                  const int2 *__restrict__ ry, const int2 *__restrict__ rz,
-                                                 const int czg0) {
+                                                 const int czg0, const int czg1) {
   const int cx = blockIdx.x * 64 + (threadIdx.x & 63) + 1;
   const int cy = blockIdx.y * 4 + (threadIdx.x >> 6) + 1;
-  const int czg = czg0 + blockIdx.z;                    // global child plane
+  const int cbeg = czg0 + blockIdx.z * ZCH, cend = min(cbeg + ZCH - 1, czg1);   // global child planes of this block
   if (cx > gs.n1 || cy > gs.n2) return;
   const int2 xr = rx[cx], yr = ry[cy];
-  int2 zr = rz[czg];
-  zr.x = max(zr.x, gd.z0 + 1) - gd.z0;                  // parent planes of this slab, local
-  zr.y = min(zr.y, gd.z0 + gd.n3) - gd.z0;
-  if (xr.x > xr.y || yr.x > yr.y || zr.x > zr.y) return;
-  const T v = mgx_stencil_prolong<T, HALF>(src, gs.idx(cx, cy, czg - gs.z0), gs.px, gs.pz);
-  for (int pz = zr.x; pz <= zr.y; ++pz)
-    for (int py = yr.x; py <= yr.y; ++py) {
-      T *row = dst + gd.idx(0, py, pz);
-      for (int px = xr.x; px <= xr.y; ++px) row[px] = v;
+  if (xr.x > xr.y || yr.x > yr.y) return;
+  typedef T pair_t __attribute__((ext_vector_type(2), aligned(sizeof(T))));   // two cells, element-aligned only
+  const bool two = xr.y - xr.x == 1;                    // the halved dimension: one store of two cells per row
+  const long long sy = gs.px;
+  T W[3][9];
+  auto fetch = [&](T (&q)[9], const int czl) {
+    const T *c = src + gs.idx(cx, cy, czl);
+#pragma unroll
+    for (int dy = -1; dy <= 1; ++dy)
+#pragma unroll
+      for (int dx = -1; dx <= 1; ++dx) q[(dy + 1) * 3 + dx + 1] = c[dx + sy * dy];
+  };
+  fetch(W[0], cbeg - 1 - gs.z0);
+  fetch(W[1], cbeg - gs.z0);
+  for (int cb = cbeg; cb <= cend; cb += 3) {
+#pragma unroll
+    for (int u = 0; u < 3; ++u) {
+      const int czg = cb + u;
+      if (czg > cend) break;
+      fetch(W[(u + 2) % 3], czg + 1 - gs.z0);
+      const T v = mgx_prolong_from_planes<T, HALF>(W[u % 3], W[(u + 1) % 3], W[(u + 2) % 3]);
+      int2 zr = rz[czg];
+      zr.x = max(zr.x, gd.z0 + 1) - gd.z0;              // parent planes of this slab, local
+      zr.y = min(zr.y, gd.z0 + gd.n3) - gd.z0;
+      pair_t vv;
+      vv.x = v;
+      vv.y = v;
+      for (int pz = zr.x; pz <= zr.y; ++pz)
+        for (int py = yr.x; py <= yr.y; ++py) {
+          T *row = dst + gd.idx(0, py, pz);
+          if (two) {
+            *reinterpret_cast<pair_t *>(row + xr.x) = vv;
+          } else {
+            for (int px = xr.x; px <= xr.y; ++px) row[px] = v;
+          }
+        }
     }
+  }
 }
 
 // generic transfer: `dst` cell (dx,dy,dz) := stencil of `src` around (mx[dx], my[dy], mz[dz]);

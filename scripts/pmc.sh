@@ -21,7 +21,7 @@ tot = collections.defaultdict(lambda: [0.0, 0])
 for f in glob.glob("$OUT/p*/**/*counter_collection.csv", recursive=True):
     for row in csv.DictReader(open(f)):
         if "k_fused_sweep" not in row["Kernel_Name"]: continue
-        key = (("box" if "true" in row["Kernel_Name"].split("k_fused_sweep")[1][:30] else "fast"), row["Counter_Name"])
+        key = (row["Kernel_Name"].split("k_fused_sweep")[1][:18], row["Counter_Name"])
         tot[key][0] += float(row["Counter_Value"]); tot[key][1] += 1
 for k in sorted(tot): print(k, "avg per launch %.4g over %d launches" % (tot[k][0] / tot[k][1], tot[k][1]))
 PY
