@@ -415,8 +415,7 @@ static int do_sweeps(mgx_level *lv, int nsweeps, int reduce) {
       if (!lv->plan.valid && mgx_fused_make_plan(lv->plan, g, lv->boxes, C(lv)->stream) != 0)
         return fail(MGX_EHIP, "mgx_level_sweep: could not build the tile lists of the fused kernel");
       if (mgx_fused_launch<T>(lv->plan, (const T *)lv->buf[lv->cur], (T *)lv->buf[1 - lv->cur], g, make_params<T>(lv),
-                              lv->d_boxes, lv->nbox, red, lv->d_res, C(lv)->stream, C(lv)->aux, C(lv)->ev_fork,
-                              C(lv)->ev_join) != 0)
+                              lv->d_boxes, lv->nbox, red, lv->d_res, C(lv)->stream) != 0)
         return fail(MGX_EHIP, "mgx_level_sweep: fused kernel launch configuration failed");
       HIP_TRY(hipGetLastError());
       lv->cur = 1 - lv->cur;

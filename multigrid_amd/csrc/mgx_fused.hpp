@@ -530,28 +530,17 @@ __device__ __forceinline__ void mgx_fused_body(const T *__restrict__ src, T *__r
   if (reduce) mgx_block_commit<NW + 1>((double)(err * err), slo, shi, ovf, reduce, res);
 }
 
-// One launch per tile class: `tiles` lists the tiles (x fastest, then y, then z chunk) that boxes do not
-// reach (BOXES = 0), that only boxes with rho = 1 reach (1), or that some box with rho != 1 reaches (2); the host
-// builds the three lists from the box table.
+// One launch per sweep.  `tiles` lists the tiles (x fastest, then y, then z chunk) in three segments, each padded
+// with -1 to a multiple of 8 blocks: tiles that some box with rho != 1 reaches (they take longest, so they are
+// dispatched first), tiles that only boxes with rho = 1 reach, tiles no box reaches.  The host builds the list
+// from the box table.
 template <typename T, int TY, int BOXES, int NW>
-__global__ __launch_bounds__((NW + 1) * 64) void k_fused_sweep(const T *__restrict__ src, T *__restrict__ dst, const MgxGeom g,
-                                                     const MgxSweepParams<T> p, const MgxBox *__restrict__ bx,
-                                                     const int nb, const int ZC, const int ntx, const int nty,
-                                                     const int *__restrict__ tiles, const int reduce,
-                                                     u64 *__restrict__ res) {
+__device__ __forceinline__ void mgx_fused_tile(const T *__restrict__ src, T *__restrict__ dst, const MgxGeom &g,
+                                               const MgxSweepParams<T> &p, const MgxBox *__restrict__ bx, const int nb,
+                                               const int ZC, const int ntx, const int nty, const int tile, const int reduce,
+                                               u64 *__restrict__ res, T *__restrict__ lds, MgxBoxLds<T> *__restrict__ bl) {
   constexpr int TXP = 64;
-  extern __shared__ __align__(16) unsigned char mgx_lds_raw[];
-  T *lds = reinterpret_cast<T *>(mgx_lds_raw);          // [slot 0..2][comp 0..1][pairs of a staged plane]
-  MgxBoxLds<T> *bl = reinterpret_cast<MgxBoxLds<T> *>(lds + 3 * 2 * (TXP + 2) * (TY + 6));
-
-  // blocks that share an XCD (same blockIdx % 8) get consecutive list entries, i.e. neighbouring tiles
-  int lid;
-  {
-    const int nblk = gridDim.x, b = blockIdx.x, xcd = b & 7, q = nblk >> 3, r = nblk & 7;
-    lid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (b >> 3);
-  }
-  lid = tiles[lid];
-  const int tx = lid % ntx, ty = (lid / ntx) % nty, tz = lid / (ntx * nty);
+  const int tx = tile % ntx, ty = (tile / ntx) % nty, tz = tile / (ntx * nty);
   const int tx0 = 1 + tx * 2 * TXP, ty0 = 1 + ty * TY;
   const int zc0 = 1 + tz * ZC, zc1 = min(zc0 + ZC - 1, g.n3);
   // parity of y + z (global) of the wave's first item on the first plane of the march, zc0 - 1
@@ -567,13 +556,38 @@ __global__ __launch_bounds__((NW + 1) * 64) void k_fused_sweep(const T *__restri
   }
 }
 
+template <typename T, int TY, int NW>
+__global__ __launch_bounds__((NW + 1) * 64) void k_fused_sweep(const T *__restrict__ src, T *__restrict__ dst, const MgxGeom g,
+                                                     const MgxSweepParams<T> p, const MgxBox *__restrict__ bx,
+                                                     const int nb, const int ZC, const int ntx, const int nty,
+                                                     const int *__restrict__ tiles, const int n_box, const int n_const,
+                                                     const int reduce, u64 *__restrict__ res) {
+  constexpr int TXP = 64;
+  extern __shared__ __align__(16) unsigned char mgx_lds_raw[];
+  T *lds = reinterpret_cast<T *>(mgx_lds_raw);          // [slot 0..2][black, red][pairs of a staged plane]
+  MgxBoxLds<T> *bl = reinterpret_cast<MgxBoxLds<T> *>(lds + 3 * 2 * (TXP + 2) * (TY + 6));
+
+  // segment of this block (all three sizes are multiples of 8); inside a segment the blocks that share an XCD
+  // (same blockIdx % 8) get consecutive list entries, i.e. neighbouring tiles
+  const int b = blockIdx.x;
+  const int cls = b < n_box ? 2 : b < n_box + n_const ? 1 : 0;
+  const int base = cls == 2 ? 0 : cls == 1 ? n_box : n_box + n_const;
+  const int cnt = cls == 2 ? n_box : cls == 1 ? n_const : (int)gridDim.x - base;
+  const int bs = b - base;
+  const int tile = tiles[base + (bs & 7) * (cnt >> 3) + (bs >> 3)];
+  if (tile < 0) return;                                 // padding (the whole block leaves before any barrier)
+  if (cls == 2) mgx_fused_tile<T, TY, 2, NW>(src, dst, g, p, bx, nb, ZC, ntx, nty, tile, reduce, res, lds, bl);
+  else if (cls == 1) mgx_fused_tile<T, TY, 1, NW>(src, dst, g, p, bx, nb, ZC, ntx, nty, tile, reduce, res, lds, bl);
+  else mgx_fused_tile<T, TY, 0, NW>(src, dst, g, p, bx, nb, ZC, ntx, nty, tile, reduce, res, lds, bl);
+}
+
 // ------------------------------------------------------------------------------------------------
 // host side
 
-struct MgxFusedPlan {            // per level: tile decomposition and the two tile lists (device)
+struct MgxFusedPlan {            // per level: tile decomposition and the tile list (device)
   int ty = 0, nw = 4, ZC = 0, ntx = 0, nty = 0, nzc = 0;
-  int n_fast = 0, n_const = 0, n_box = 0;
-  int *d_tiles = nullptr;        // n_fast entries, then n_const, then n_box entries
+  int n_fast = 0, n_const = 0, n_box = 0;   // segment sizes, each padded to a multiple of 8
+  int *d_tiles = nullptr;        // n_box entries, then n_const, then n_fast entries; -1 = padding
   bool valid = false;
 };
 
@@ -621,51 +635,35 @@ static int mgx_fused_make_plan(MgxFusedPlan &pl, const MgxGeom &g, const std::ve
         }
         (hit_rho ? boxed : hit ? consto : fast).push_back((tz * pl.nty + ty) * pl.ntx + tx);
       }
+  for (std::vector<int> *v : {&boxed, &consto, &fast})
+    while (v->size() % 8) v->push_back(-1);
   pl.n_fast = (int)fast.size();
   pl.n_const = (int)consto.size();
   pl.n_box = (int)boxed.size();
-  fast.insert(fast.end(), consto.begin(), consto.end());
-  fast.insert(fast.end(), boxed.begin(), boxed.end());
-  if (hipMalloc((void **)&pl.d_tiles, sizeof(int) * fast.size()) != hipSuccess) return -1;
-  if (hipMemcpyAsync(pl.d_tiles, fast.data(), sizeof(int) * fast.size(), hipMemcpyHostToDevice, st) != hipSuccess) return -1;
-  if (hipStreamSynchronize(st) != hipSuccess) return -1;     // `fast` goes out of scope
+  std::vector<int> all(boxed);
+  all.insert(all.end(), consto.begin(), consto.end());
+  all.insert(all.end(), fast.begin(), fast.end());
+  if (hipMalloc((void **)&pl.d_tiles, sizeof(int) * all.size()) != hipSuccess) return -1;
+  if (hipMemcpyAsync(pl.d_tiles, all.data(), sizeof(int) * all.size(), hipMemcpyHostToDevice, st) != hipSuccess) return -1;
+  if (hipStreamSynchronize(st) != hipSuccess) return -1;     // `all` goes out of scope
   pl.valid = true;
   return 0;
 }
 
 template <typename T, int TY, int NW>
 static int mgx_fused_launch_cfg(const MgxFusedPlan &pl, const T *src, T *dst, const MgxGeom &g, const MgxSweepParams<T> &p,
-                                const MgxBox *bx, int nb, int reduce, u64 *res, hipStream_t st, hipStream_t aux, hipEvent_t ev_fork,
-                                hipEvent_t ev_join) {
+                                const MgxBox *bx, int nb, int reduce, u64 *res, hipStream_t st) {
   constexpr int TXP = 64;
   constexpr size_t lds = (size_t)3 * 2 * (TXP + 2) * (TY + 6) * sizeof(T) + sizeof(MgxBoxLds<T>);
-  if (lds > 64 * 1024) {      // beyond the default dynamic LDS limit: raise it for both kernels
-    if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_fused_sweep<T, TY, 0, NW>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
-        hipFuncSetAttribute(reinterpret_cast<const void *>(k_fused_sweep<T, TY, 1, NW>),
-                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess ||
-        hipFuncSetAttribute(reinterpret_cast<const void *>(k_fused_sweep<T, TY, 2, NW>),
+  if (lds > 64 * 1024) {        // beyond the default dynamic LDS limit (the attribute is per device)
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_fused_sweep<T, TY, NW>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
       return -1;
   }
-  // The (few, slower) tiles that boxes reach run on the side stream, concurrently with the others.
-  const bool side = pl.n_box > 0 && pl.n_fast + pl.n_const > 0 && aux != nullptr;
-  hipStream_t sb = side ? aux : st;
-  if (side) {
-    if (hipEventRecord(ev_fork, st) != hipSuccess || hipStreamWaitEvent(aux, ev_fork, 0) != hipSuccess) return -1;
-  }
-  if (pl.n_box > 0)
-    hipLaunchKernelGGL((k_fused_sweep<T, TY, 2, NW>), dim3((unsigned)pl.n_box), dim3((NW + 1) * 64), lds, sb, src, dst, g, p, bx, nb,
-                       pl.ZC, pl.ntx, pl.nty, pl.d_tiles + pl.n_fast + pl.n_const, reduce, res);
-  if (pl.n_const > 0)
-    hipLaunchKernelGGL((k_fused_sweep<T, TY, 1, NW>), dim3((unsigned)pl.n_const), dim3((NW + 1) * 64), lds, st, src, dst, g, p, bx, nb,
-                       pl.ZC, pl.ntx, pl.nty, pl.d_tiles + pl.n_fast, reduce, res);
-  if (pl.n_fast > 0)
-    hipLaunchKernelGGL((k_fused_sweep<T, TY, 0, NW>), dim3((unsigned)pl.n_fast), dim3((NW + 1) * 64), lds, st, src, dst, g, p, bx, nb,
-                       pl.ZC, pl.ntx, pl.nty, pl.d_tiles, reduce, res);
-  if (side) {
-    if (hipEventRecord(ev_join, aux) != hipSuccess || hipStreamWaitEvent(st, ev_join, 0) != hipSuccess) return -1;
-  }
+  const int total = pl.n_box + pl.n_const + pl.n_fast;
+  if (total > 0)
+    hipLaunchKernelGGL((k_fused_sweep<T, TY, NW>), dim3((unsigned)total), dim3((NW + 1) * 64), lds, st, src, dst, g, p, bx, nb,
+                       pl.ZC, pl.ntx, pl.nty, pl.d_tiles, pl.n_box, pl.n_const, reduce, res);
   return 0;
 }
 
@@ -679,11 +677,10 @@ static bool mgx_fused_supported(const MgxGeom &g, int nbox) {
 
 template <typename T>
 static int mgx_fused_launch(const MgxFusedPlan &pl, const T *src, T *dst, const MgxGeom &g, const MgxSweepParams<T> &p,
-                            const MgxBox *bx, int nb, int reduce, u64 *res, hipStream_t st, hipStream_t aux,
-                            hipEvent_t ev_fork, hipEvent_t ev_join) {
+                            const MgxBox *bx, int nb, int reduce, u64 *res, hipStream_t st) {
   switch (pl.ty * 100 + pl.nw) {
-    case 1208: return mgx_fused_launch_cfg<T, 12, 8>(pl, src, dst, g, p, bx, nb, reduce, res, st, aux, ev_fork, ev_join);
-    case 2008: return mgx_fused_launch_cfg<T, 20, 8>(pl, src, dst, g, p, bx, nb, reduce, res, st, aux, ev_fork, ev_join);
-    default: return mgx_fused_launch_cfg<T, 8, 4>(pl, src, dst, g, p, bx, nb, reduce, res, st, aux, ev_fork, ev_join);
+    case 1208: return mgx_fused_launch_cfg<T, 12, 8>(pl, src, dst, g, p, bx, nb, reduce, res, st);
+    case 2008: return mgx_fused_launch_cfg<T, 20, 8>(pl, src, dst, g, p, bx, nb, reduce, res, st);
+    default: return mgx_fused_launch_cfg<T, 8, 4>(pl, src, dst, g, p, bx, nb, reduce, res, st);
   }
 }

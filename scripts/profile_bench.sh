@@ -28,7 +28,7 @@ for f in glob.glob("$OUT/pmc_*/**/*counter_collection.csv", recursive=True):
 # one sweep = the launches of all tile classes; count launches of the no-box class = number of sweeps
 n_sweeps = None
 for f in glob.glob("$OUT/pmc_FETCH_SIZE/**/*counter_collection.csv", recursive=True):
-    n_sweeps = sum(1 for row in csv.DictReader(open(f)) if "k_fused_sweep" in row["Kernel_Name"] and "Li0ELi8" in row["Kernel_Name"] or "<double, 20, 0, 8>" in row["Kernel_Name"])
+    n_sweeps = sum(1 for row in csv.DictReader(open(f)) if "k_fused_sweep" in row["Kernel_Name"])
 out["pmc_totals"] = {k: v[0] for k, v in tot.items()}
 out["pmc_launches"] = {k: v[1] for k, v in tot.items()}
 out["n_sweeps_seen"] = n_sweeps
