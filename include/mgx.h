@@ -52,6 +52,8 @@ enum { MGX_BC_PERIODIC = 1, MGX_BC_DIRICHLET = 2, MGX_BC_NEUMANN = 3 };
 enum { MGX_INTERP_FULL = 1, MGX_INTERP_HALF = 2 };
 /* which reductions a sweep accumulates */
 enum { MGX_RED_ERR = 1, MGX_RED_SUM = 2 };
+/* the two launches of mgx_level_sweep_part */
+enum { MGX_PART_EDGE = 1, MGX_PART_INNER = 2 };
 /* sweep kernel selection (results are bit-identical; for benchmarking) */
 enum { MGX_KERNEL_AUTO = 0, MGX_KERNEL_TWO_PASS = 1, MGX_KERNEL_FUSED = 2 };
 
@@ -106,6 +108,14 @@ int mgx_level_setup(mgx_level *lv, int init);
  * (mgx_level_plane_ptr; no other call is needed after such an exchange).  Reductions cover the
  * slab's own planes. */
 int mgx_level_sweep(mgx_level *lv, int nsweeps, int reduce);
+/* The same sweep (one, fused kernel) in two launches, for z slabs that overlap the halo exchange with the bulk
+ * of the sweep: MGX_PART_EDGE sweeps the first and the last z chunk (which hold planes 1, 2 and n3-1, n3) and
+ * makes the new field the current one (mgx_level_plane_ptr then returns its planes: send 1, 2 and n3-1, n3,
+ * receive into -1, 0 and n3+1, n3+2); MGX_PART_INNER sweeps the remaining planes from the same old field and may
+ * run while the planes travel.  Every call of the first kind must be followed by one of the second before any
+ * other operation on the level.  `reduce` as in mgx_level_sweep, the same value in both calls.  No counterpart in
+ * the reference (its sweep runs in one address space). */
+int mgx_level_sweep_part(mgx_level *lv, int part, int reduce);
 /* one colour only (parity 1 = odd x+y+z, 0 = even), planes [zlo,zhi] (local, 1-based,
  * inclusive) — the building block for halo-exchange overlap across z-slabs.
  * Reductions accumulate into the level's result until mgx_level_result_reset. */

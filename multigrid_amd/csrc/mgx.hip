@@ -66,6 +66,7 @@ struct mgx_level {
   int cur = 0;
   bool shell_synced = false;   // buf[1-cur] holds the same ghost shell as buf[cur]
   bool defined = false;        // field content is meaningful
+  bool inner_pending = false;  // mgx_level_sweep_part: the edge part ran, the inner part is due
   bool zero_pending = false;   // brought back but not yet zero-filled: the next reader fills, a full overwrite skips it
   // parameters
   double sor = 1.8;
@@ -414,7 +415,7 @@ static int do_sweeps(mgx_level *lv, int nsweeps, int reduce) {
       TRY(sync_shell<T>(lv));
       if (!lv->plan.valid && mgx_fused_make_plan(lv->plan, g, lv->boxes, C(lv)->stream) != 0)
         return fail(MGX_EHIP, "mgx_level_sweep: could not build the tile lists of the fused kernel");
-      if (mgx_fused_launch<T>(lv->plan, (const T *)lv->buf[lv->cur], (T *)lv->buf[1 - lv->cur], g, make_params<T>(lv),
+      if (mgx_fused_launch<T>(lv->plan, 0, (const T *)lv->buf[lv->cur], (T *)lv->buf[1 - lv->cur], g, make_params<T>(lv),
                               lv->d_boxes, lv->nbox, red, lv->d_res, C(lv)->stream) != 0)
         return fail(MGX_EHIP, "mgx_level_sweep: fused kernel launch configuration failed");
       HIP_TRY(hipGetLastError());
@@ -444,6 +445,48 @@ extern "C" int mgx_level_sweep(mgx_level *lv, int nsweeps, int reduce) {
   TRY(set_device(C(lv)));
   TRY(materialize(lv));
   return lv->elem == 4 ? do_sweeps<float>(lv, nsweeps, reduce) : do_sweeps<double>(lv, nsweeps, reduce);
+}
+
+// One fused sweep in two launches.  Part 1 (MGX_PART_EDGE) sweeps the first and the last z chunk of the level or slab
+// and makes the new field the current one, so that mgx_level_plane_ptr hands out the planes a neighbour is waiting for;
+// part 2 (MGX_PART_INNER) sweeps the rest from the same old field while those planes travel.
+template <typename T>
+static int do_sweep_part(mgx_level *lv, int part, int reduce) {
+  const MgxGeom &g = lv->g;
+  if (!mgx_fused_supported<T>(g, lv->nbox) || C(lv)->kernel == MGX_KERNEL_TWO_PASS)
+    return fail(MGX_ESTATE, "mgx_level_sweep_part: needs the fused kernel (at most %d boxes, kernel not forced to two-pass)",
+                MGX_MAX_FUSED_BOXES);
+  if (part == MGX_PART_EDGE) {
+    if (lv->inner_pending) return fail(MGX_ESTATE, "mgx_level_sweep_part: the inner part of the previous sweep is still due");
+    if (reduce) TRY(reset_result(lv));
+    TRY(sync_shell<T>(lv));
+    if (!lv->plan.valid && mgx_fused_make_plan(lv->plan, g, lv->boxes, C(lv)->stream) != 0)
+      return fail(MGX_EHIP, "mgx_level_sweep_part: could not build the tile lists of the fused kernel");
+    if (mgx_fused_launch<T>(lv->plan, 1, (const T *)lv->buf[lv->cur], (T *)lv->buf[1 - lv->cur], g, make_params<T>(lv),
+                            lv->d_boxes, lv->nbox, reduce, lv->d_res, C(lv)->stream) != 0)
+      return fail(MGX_EHIP, "mgx_level_sweep_part: fused kernel launch configuration failed");
+    HIP_TRY(hipGetLastError());
+    lv->cur = 1 - lv->cur;
+    lv->inner_pending = true;
+  } else {
+    if (!lv->inner_pending) return fail(MGX_ESTATE, "mgx_level_sweep_part: the inner part follows the edge part");
+    if (mgx_fused_launch<T>(lv->plan, 2, (const T *)lv->buf[1 - lv->cur], (T *)lv->buf[lv->cur], g, make_params<T>(lv),
+                            lv->d_boxes, lv->nbox, reduce, lv->d_res, C(lv)->stream) != 0)
+      return fail(MGX_EHIP, "mgx_level_sweep_part: fused kernel launch configuration failed");
+    HIP_TRY(hipGetLastError());
+    lv->inner_pending = false;
+  }
+  return MGX_OK;
+}
+
+extern "C" int mgx_level_sweep_part(mgx_level *lv, int part, int reduce) {
+  if (!lv) return fail(MGX_EINVAL, "mgx_level_sweep_part: NULL level");
+  if (part != MGX_PART_EDGE && part != MGX_PART_INNER) return fail(MGX_EINVAL, "mgx_level_sweep_part: part = %d", part);
+  if (!lv->params_set) return fail(MGX_ESTATE, "mgx_level_sweep_part: mgx_level_set_params not called");
+  if (!lv->defined) return fail(MGX_ESTATE, "mgx_level_sweep_part: level %d was released", lv->layer);
+  TRY(set_device(C(lv)));
+  TRY(materialize(lv));
+  return lv->elem == 4 ? do_sweep_part<float>(lv, part, reduce) : do_sweep_part<double>(lv, part, reduce);
 }
 
 extern "C" int mgx_level_half_sweep(mgx_level *lv, int parity, int32_t zlo, int32_t zhi, int reduce) {

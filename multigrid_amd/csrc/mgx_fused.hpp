@@ -584,10 +584,17 @@ __global__ __launch_bounds__((NW + 1) * 64) void k_fused_sweep(const T *__restri
 // ------------------------------------------------------------------------------------------------
 // host side
 
-struct MgxFusedPlan {            // per level: tile decomposition and the tile list (device)
+struct MgxTileList {             // segment sizes, each padded to a multiple of 8, and where the list starts
+  int n_fast = 0, n_const = 0, n_box = 0;
+  int offset = 0;                // into MgxFusedPlan::d_tiles: n_box entries, then n_const, then n_fast; -1 = padding
+};
+
+struct MgxFusedPlan {            // per level: tile decomposition and the tile lists (device)
   int ty = 0, nw = 4, ZC = 0, ntx = 0, nty = 0, nzc = 0;
-  int n_fast = 0, n_const = 0, n_box = 0;   // segment sizes, each padded to a multiple of 8
-  int *d_tiles = nullptr;        // n_box entries, then n_const, then n_fast entries; -1 = padding
+  // [0] every tile; [1] the tiles of the first and the last z chunk (they make the planes a z slab sends to its
+  // neighbours); [2] the others
+  MgxTileList list[3];
+  int *d_tiles = nullptr;
   bool valid = false;
 };
 
@@ -620,30 +627,39 @@ static int mgx_fused_make_plan(MgxFusedPlan &pl, const MgxGeom &g, const std::ve
   pl.nzc = (g.n3 + ZC - 1) / ZC;
   const long long ntile = per_chunk * pl.nzc;
   if (ntile > 0x7fffffffLL) return -1;
-  std::vector<int> fast, consto, boxed;   // no box in reach / only rho = 1 boxes / some box with rho != 1
-  for (int tz = 0; tz < pl.nzc; ++tz)
-    for (int ty = 0; ty < pl.nty; ++ty)
-      for (int tx = 0; tx < pl.ntx; ++tx) {
-        const int x0 = 1 + tx * 2 * TXP - 2, x1 = 1 + (tx + 1) * 2 * TXP + 1;
-        const int y0 = 1 + ty * pl.ty - 2, y1 = 1 + (ty + 1) * pl.ty + 1;
-        const int zc0 = 1 + tz * ZC, zc1 = std::min(zc0 + ZC - 1, g.n3);
-        const int z0 = zc0 - 2 + g.z0, z1 = zc1 + 2 + g.z0;
-        bool hit = false, hit_rho = false;
-        for (const MgxBox &b : boxes) {
-          const bool h = b.lo[0] <= x1 && x0 <= b.hi[0] && b.lo[1] <= y1 && y0 <= b.hi[1] && b.lo[2] <= z1 && z0 <= b.hi[2];
-          hit |= h;
-          hit_rho |= h && !b.rho_is_one;
+  std::vector<int> all;
+  for (int sel = 0; sel < 3; ++sel) {
+    std::vector<int> fast, consto, boxed;   // no box in reach / only rho = 1 boxes / some box with rho != 1
+    for (int tz = 0; tz < pl.nzc; ++tz) {
+      const bool edge = tz == 0 || tz == pl.nzc - 1;
+      if ((sel == 1 && !edge) || (sel == 2 && edge)) continue;
+      for (int ty = 0; ty < pl.nty; ++ty)
+        for (int tx = 0; tx < pl.ntx; ++tx) {
+          const int x0 = 1 + tx * 2 * TXP - 2, x1 = 1 + (tx + 1) * 2 * TXP + 1;
+          const int y0 = 1 + ty * pl.ty - 2, y1 = 1 + (ty + 1) * pl.ty + 1;
+          const int zc0 = 1 + tz * ZC, zc1 = std::min(zc0 + ZC - 1, g.n3);
+          const int z0 = zc0 - 2 + g.z0, z1 = zc1 + 2 + g.z0;
+          bool hit = false, hit_rho = false;
+          for (const MgxBox &b : boxes) {
+            const bool h = b.lo[0] <= x1 && x0 <= b.hi[0] && b.lo[1] <= y1 && y0 <= b.hi[1] && b.lo[2] <= z1 && z0 <= b.hi[2];
+            hit |= h;
+            hit_rho |= h && !b.rho_is_one;
+          }
+          (hit_rho ? boxed : hit ? consto : fast).push_back((tz * pl.nty + ty) * pl.ntx + tx);
         }
-        (hit_rho ? boxed : hit ? consto : fast).push_back((tz * pl.nty + ty) * pl.ntx + tx);
-      }
-  for (std::vector<int> *v : {&boxed, &consto, &fast})
-    while (v->size() % 8) v->push_back(-1);
-  pl.n_fast = (int)fast.size();
-  pl.n_const = (int)consto.size();
-  pl.n_box = (int)boxed.size();
-  std::vector<int> all(boxed);
-  all.insert(all.end(), consto.begin(), consto.end());
-  all.insert(all.end(), fast.begin(), fast.end());
+    }
+    for (std::vector<int> *v : {&boxed, &consto, &fast})
+      while (v->size() % 8) v->push_back(-1);
+    MgxTileList &tl = pl.list[sel];
+    tl.n_fast = (int)fast.size();
+    tl.n_const = (int)consto.size();
+    tl.n_box = (int)boxed.size();
+    tl.offset = (int)all.size();
+    all.insert(all.end(), boxed.begin(), boxed.end());
+    all.insert(all.end(), consto.begin(), consto.end());
+    all.insert(all.end(), fast.begin(), fast.end());
+  }
+  if (all.empty()) all.push_back(-1);
   if (hipMalloc((void **)&pl.d_tiles, sizeof(int) * all.size()) != hipSuccess) return -1;
   if (hipMemcpyAsync(pl.d_tiles, all.data(), sizeof(int) * all.size(), hipMemcpyHostToDevice, st) != hipSuccess) return -1;
   if (hipStreamSynchronize(st) != hipSuccess) return -1;     // `all` goes out of scope
@@ -652,8 +668,8 @@ static int mgx_fused_make_plan(MgxFusedPlan &pl, const MgxGeom &g, const std::ve
 }
 
 template <typename T, int TY, int NW>
-static int mgx_fused_launch_cfg(const MgxFusedPlan &pl, const T *src, T *dst, const MgxGeom &g, const MgxSweepParams<T> &p,
-                                const MgxBox *bx, int nb, int reduce, u64 *res, hipStream_t st) {
+static int mgx_fused_launch_cfg(const MgxFusedPlan &pl, int part, const T *src, T *dst, const MgxGeom &g,
+                                const MgxSweepParams<T> &p, const MgxBox *bx, int nb, int reduce, u64 *res, hipStream_t st) {
   constexpr int TXP = 64;
   constexpr size_t lds = (size_t)3 * 2 * (TXP + 2) * (TY + 6) * sizeof(T) + sizeof(MgxBoxLds<T>);
   if (lds > 64 * 1024) {        // beyond the default dynamic LDS limit (the attribute is per device)
@@ -661,10 +677,11 @@ static int mgx_fused_launch_cfg(const MgxFusedPlan &pl, const T *src, T *dst, co
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
       return -1;
   }
-  const int total = pl.n_box + pl.n_const + pl.n_fast;
+  const MgxTileList &tl = pl.list[part];
+  const int total = tl.n_box + tl.n_const + tl.n_fast;
   if (total > 0)
     hipLaunchKernelGGL((k_fused_sweep<T, TY, NW>), dim3((unsigned)total), dim3((NW + 1) * 64), lds, st, src, dst, g, p, bx, nb,
-                       pl.ZC, pl.ntx, pl.nty, pl.d_tiles, pl.n_box, pl.n_const, reduce, res);
+                       pl.ZC, pl.ntx, pl.nty, pl.d_tiles + tl.offset, tl.n_box, tl.n_const, reduce, res);
   return 0;
 }
 
@@ -677,11 +694,11 @@ static bool mgx_fused_supported(const MgxGeom &g, int nbox) {
 }
 
 template <typename T>
-static int mgx_fused_launch(const MgxFusedPlan &pl, const T *src, T *dst, const MgxGeom &g, const MgxSweepParams<T> &p,
-                            const MgxBox *bx, int nb, int reduce, u64 *res, hipStream_t st) {
+static int mgx_fused_launch(const MgxFusedPlan &pl, int part, const T *src, T *dst, const MgxGeom &g,
+                            const MgxSweepParams<T> &p, const MgxBox *bx, int nb, int reduce, u64 *res, hipStream_t st) {
   switch (pl.ty * 100 + pl.nw) {
-    case 1208: return mgx_fused_launch_cfg<T, 12, 8>(pl, src, dst, g, p, bx, nb, reduce, res, st);
-    case 2008: return mgx_fused_launch_cfg<T, 20, 8>(pl, src, dst, g, p, bx, nb, reduce, res, st);
-    default: return mgx_fused_launch_cfg<T, 8, 4>(pl, src, dst, g, p, bx, nb, reduce, res, st);
+    case 1208: return mgx_fused_launch_cfg<T, 12, 8>(pl, part, src, dst, g, p, bx, nb, reduce, res, st);
+    case 2008: return mgx_fused_launch_cfg<T, 20, 8>(pl, part, src, dst, g, p, bx, nb, reduce, res, st);
+    default: return mgx_fused_launch_cfg<T, 8, 4>(pl, part, src, dst, g, p, bx, nb, reduce, res, st);
   }
 }

@@ -7,6 +7,7 @@ module mgx_c
   public
 
   integer(c_int), parameter :: MGX_RED_ERR = 1, MGX_RED_SUM = 2
+  integer(c_int), parameter :: MGX_PART_EDGE = 1, MGX_PART_INNER = 2
   integer(c_int), parameter :: MGX_KERNEL_AUTO = 0, MGX_KERNEL_TWO_PASS = 1, MGX_KERNEL_FUSED = 2
 
   interface
@@ -99,6 +100,12 @@ module mgx_c
        integer(c_int), value :: nsweeps, reduce
        integer(c_int) :: rc
      end function mgx_level_sweep
+     function mgx_level_sweep_part(lv, part, reduce) bind(C, name="mgx_level_sweep_part") result(rc)
+       import :: c_int, c_ptr
+       type(c_ptr), value :: lv
+       integer(c_int), value :: part, reduce
+       integer(c_int) :: rc
+     end function mgx_level_sweep_part
      function mgx_level_half_sweep(lv, parity, zlo, zhi, reduce) bind(C, name="mgx_level_half_sweep") result(rc)
        import :: c_int, c_int32_t, c_ptr
        type(c_ptr), value :: lv

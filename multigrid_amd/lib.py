@@ -18,11 +18,13 @@ RED_ERR, RED_SUM = 1, 2
 KERNEL_AUTO, KERNEL_TWO_PASS, KERNEL_FUSED = 0, 1, 2
 INTERP_FULL, INTERP_HALF = 1, 2
 BC_PERIODIC, BC_DIRICHLET, BC_NEUMANN = 1, 2, 3
+PART_EDGE, PART_INNER = 1, 2
 
 SYMBOLS = [
     "mgx_last_error", "mgx_version", "mgx_ctx_create", "mgx_ctx_destroy", "mgx_ctx_sync", "mgx_ctx_set_kernel",
     "mgx_level_create", "mgx_level_create_slab", "mgx_level_destroy", "mgx_level_bring_back", "mgx_level_release",
-    "mgx_level_set_params", "mgx_level_set_boxes", "mgx_level_setup", "mgx_level_sweep", "mgx_level_half_sweep",
+    "mgx_level_set_params", "mgx_level_set_boxes", "mgx_level_setup", "mgx_level_sweep", "mgx_level_sweep_part",
+    "mgx_level_half_sweep",
     "mgx_level_result_reset", "mgx_level_result", "mgx_level_abs_sum", "mgx_level_abs_sum_limbs",
     "mgx_limbs_to_double", "mgx_level_count_nonconst", "mgx_level_tolerance", "mgx_restrict", "mgx_prolong",
     "mgx_level_upload", "mgx_level_download", "mgx_level_plane_ptr", "mgx_level_halo_written", "mgx_level_info",
@@ -63,6 +65,7 @@ def load():
         "mgx_level_set_boxes": [vp, i32, pi32, pdbl, pdbl, pi32],
         "mgx_level_setup": [vp, C.c_int],
         "mgx_level_sweep": [vp, C.c_int, C.c_int],
+        "mgx_level_sweep_part": [vp, C.c_int, C.c_int],
         "mgx_level_half_sweep": [vp, C.c_int, i32, i32, C.c_int],
         "mgx_level_result_reset": [vp],
         "mgx_level_result": [vp, pdbl, pdbl, pu64],
@@ -177,6 +180,9 @@ class DeviceLevel:
 
     def sweep(self, nsweeps: int = 1, reduce: int = RED_ERR | RED_SUM):
         _ck(self.L.mgx_level_sweep(self.h, int(nsweeps), int(reduce)))
+
+    def sweep_part(self, part: int, reduce: int = RED_ERR | RED_SUM):
+        _ck(self.L.mgx_level_sweep_part(self.h, int(part), int(reduce)))
 
     def half_sweep(self, parity: int, zlo: int, zhi: int, reduce: int = 0):
         _ck(self.L.mgx_level_half_sweep(self.h, int(parity), int(zlo), int(zhi), int(reduce)))

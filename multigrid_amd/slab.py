@@ -16,8 +16,8 @@ Reductions: max (vv-V)^2 is a MAX all-reduce; sum |V| is the exact integer sum
 (units of 2^-72), sent as four 32-bit digits in int64 and added with a SUM all-reduce, so the
 result has the same bits for any number of ranks.
 
-The level object behind a slab only needs: setup(init), sweep(1, reduce), result(),
-halo_written(), plane_tensor(z, count); multigrid_amd.lib.DeviceLevel provides them on the GPU.
+The level object behind a slab only needs: setup(init), sweep(1, reduce), sweep_part(part, reduce),
+result(), halo_written(), plane_tensor(z, count); multigrid_amd.lib.DeviceLevel provides them on the GPU.
 """
 from __future__ import annotations
 
@@ -60,7 +60,7 @@ class SlabLevel:
     """one rank's slab of a level + the halo exchange and the all-reduced reductions"""
 
     def __init__(self, ctx, top: G.MgGrid, rank: int, world: int, group=None,
-                 level_factory: Optional[Callable] = None, plane_tensor: Optional[Callable] = None):
+                 level_factory: Optional[Callable] = None, plane_tensor: Optional[Callable] = None, overlap: bool = True):
         import torch.distributed as dist
         self.dist = dist
         self.rank, self.world, self.group = int(rank), int(world), group
@@ -80,6 +80,7 @@ class SlabLevel:
         self.upper = rank + 1 if rank < world - 1 else None
         self.periodic_z = top.bc6()[4] == lib.BC_PERIODIC or top.bc6()[5] == lib.BC_PERIODIC
         self.reduce = lib.RED_ERR | lib.RED_SUM
+        self.overlap = overlap and hasattr(self.lv, "sweep_part")
 
     # ---- communication -------------------------------------------------------------------------
     def planes(self, z: int, count: int):
@@ -92,8 +93,12 @@ class SlabLevel:
 
     def exchange_halos(self):
         """new planes 1,2 -> lower neighbour's n3+1,n3+2; new planes n3-1,n3 -> upper neighbour's -1,0"""
+        for w in self._start_exchange():
+            w.wait()
+
+    def _start_exchange(self):
         if self.world == 1:
-            return
+            return []
         P, d, ops = self.dist.P2POp, self.dist, []
         # every rank lists its ops lower-neighbour first: matching order on both sides of a link
         if self.lower is not None:
@@ -102,7 +107,7 @@ class SlabLevel:
         if self.upper is not None:
             ops.append(P(d.irecv, self.planes(self.n3 + 1, 2), self.upper, self.group))
             ops.append(P(d.isend, self.planes(self.n3 - 1, 2), self.upper, self.group))
-        self._run(ops)
+        return self.dist.batch_isend_irecv(ops) if ops else []
 
     def _exchange_periodic_ghosts(self):
         """grid_setup's periodic C faces (t_mg.f90:553-583): ghost plane 0 = plane n3g, ghost plane n3g+1 = plane 1,
@@ -136,9 +141,20 @@ class SlabLevel:
         self.lv.halo_written()
 
     def sweep(self, reduce: Optional[int] = None):
-        """one red-black sweep of the whole level (gs_step, m_gs_CDS.F90:296-315)"""
-        self.lv.sweep(1, self.reduce if reduce is None else reduce)
-        self.exchange_halos()
+        """one red-black sweep of the whole level (gs_step, m_gs_CDS.F90:296-315).  The first and the last z chunk
+        of the slab are swept first; their new planes travel to the neighbours while the rest of the slab is swept
+        (the communication backend orders its transfers after the kernels already enqueued on the current stream,
+        so the inner launch, enqueued afterwards, runs beside them)."""
+        red = self.reduce if reduce is None else reduce
+        if self.world == 1 or not self.overlap:
+            self.lv.sweep(1, red)
+            self.exchange_halos()
+            return
+        self.lv.sweep_part(lib.PART_EDGE, red)
+        works = self._start_exchange()
+        self.lv.sweep_part(lib.PART_INNER, red)
+        for w in works:
+            w.wait()
 
     def result(self):
         """(max (vv-V)^2, sum|V|, exact sum in units of 2^-72) over the WHOLE level, identical on every rank"""

@@ -80,6 +80,11 @@ class FakeSlabLevel:
             s, units = orc.abs_sum_exact(orc.Level(n=(n1, n2, n3)), np.ascontiguousarray(self.V[1:n3 + 3]))
         self.res = (e2, s, units)
 
+    def sweep_part(self, part, reduce):
+        """edge part = the whole sweep (the new boundary planes exist afterwards); inner part = nothing left to do"""
+        if part == 1:
+            self.sweep(1, reduce)
+
     def result(self):
         return self.res
 

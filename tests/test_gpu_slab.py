@@ -23,15 +23,17 @@ def _levels(ctx, n, dtype, parts, bc, boxes, sor=1.6):
     return out
 
 
+# the last case is tall enough for several z chunks per slab, so that the inner launch has tiles of its own
+@pytest.mark.parametrize("two_launches", [False, True])
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
-@pytest.mark.parametrize("parts", [[(0, 13), (13, 11)], [(0, 8), (8, 7), (15, 9)]])
-def test_slab_sweeps_equal_undivided(dtype, parts):
+@pytest.mark.parametrize("parts", [[(0, 13), (13, 11)], [(0, 8), (8, 7), (15, 9)], [(0, 135), (135, 105)]])
+def test_slab_sweeps_equal_undivided(dtype, parts, two_launches):
     import torch
     from multigrid_amd import lib, slab
     from oracle import oracle as orc
-    n = (150, 45, 24)
+    n = (150, 45, sum(k for _, k in parts))
     bc = (1, 1, 1, 1, 3, 2)
-    place = np.array([[40, 110, 10, 30, 1, 2], [40, 110, 10, 30, 23, 24], [60, 90, 15, 25, 3, 22]], dtype=np.int32)
+    place = np.array([[40, 110, 10, 30, 1, 2], [40, 110, 10, 30, n[2] - 1, n[2]], [60, 90, 15, 25, 3, n[2] - 2]], dtype=np.int32)
     boxes = (place, [0.5, -0.5, 0.0], [1.0, 1.0, 3.0], [1, 1, 0])
     ctx = lib.Context(0, None)
     whole = _levels(ctx, n, dtype, [(0, n[2])], bc, boxes)[0]
@@ -65,10 +67,17 @@ def test_slab_sweeps_equal_undivided(dtype, parts):
         whole.sweep(1, 3)
         e_w, s_w, u_w = whole.result()
         assert (e_w, u_w) == (e_ref, u_ref)
-        for lv in slabs:
-            lv.sweep(1, 3)
+        if two_launches:     # edge chunks first, halo planes copied, then the rest: what a multi-GPU host overlaps
+            for lv in slabs:
+                lv.sweep_part(lib.PART_EDGE, 3)
+            exchange()
+            for lv in slabs:
+                lv.sweep_part(lib.PART_INNER, 3)
+        else:
+            for lv in slabs:
+                lv.sweep(1, 3)
+            exchange()
         res = [lv.result() for lv in slabs]
-        exchange()
         assert max(r[0] for r in res) == e_ref
         assert sum(r[2] for r in res) == u_ref
         for lv, (z0, k) in zip(slabs, parts):
