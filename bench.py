@@ -130,13 +130,15 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--n", type=int, default=512, help="cells per dimension of one GPU's slab")
+    ap.add_argument("--size", dest="n", type=int, default=512, help="cells per dimension of one GPU's slab")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-vcycle", action="store_true")
     ap.add_argument("--vcycle-tol", default="1.e-8")
     ap.add_argument("--sor", default="1.7")
     ap.add_argument("--kernel", type=int, default=0, help="0 auto, 1 two-pass, 2 fused")
     ap.add_argument("--own-stream", action="store_true", help="let the library create its stream (events then see nothing)")
+    ap.add_argument("--backend", default="nccl", help="torch.distributed backend for --gpus > 1 (nccl = RCCL)")
+    ap.add_argument("--no-overlap", action="store_true", help="exchange the halo planes after the whole sweep")
     args = ap.parse_args()
 
     import torch
@@ -148,9 +150,13 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
+    local_rank %= max(1, torch.cuda.device_count())      # rehearsals may put several ranks on one GPU
     torch.cuda.set_device(local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(args.backend)
 
     def barrier():
         if world > 1:
@@ -181,7 +187,7 @@ def main():
         from multigrid_amd import slab
         text = config3_input((n, n, n * world), tol=args.vcycle_tol, sor=args.sor)
         top = mgio.iomg_read(mgio.MgIO(text=text))
-        sl = slab.SlabLevel(ctx, top, rank, world)
+        sl = slab.SlabLevel(ctx, top, rank, world, overlap=not args.no_overlap)
         sl.setup(True)
         step = sl.sweep
         fetch = sl.result
