@@ -591,8 +591,8 @@ struct MgxTileList {             // segment sizes, each padded to a multiple of 
 
 struct MgxFusedPlan {            // per level: tile decomposition and the tile lists (device)
   int ty = 0, nw = 4, ZC = 0, ntx = 0, nty = 0, nzc = 0;
-  // [0] every tile; [1] the tiles of the first and the last z chunk (they make the planes a z slab sends to its
-  // neighbours); [2] the others
+  // [0] every tile; [1] the tiles of the z chunks that hold planes 1, 2, n3-1, n3 (the planes a z slab sends to
+  // its neighbours); [2] the others
   MgxTileList list[3];
   int *d_tiles = nullptr;
   bool valid = false;
@@ -622,6 +622,9 @@ static int mgx_fused_make_plan(MgxFusedPlan &pl, const MgxGeom &g, const std::ve
   int ZC = g.n3;
   const long long per_chunk = (long long)pl.ntx * pl.nty;
   while (ZC > 32 && per_chunk * ((g.n3 + ZC - 1) / ZC) < 768) ZC = (ZC + 1) / 2;
+  // small levels live in the caches and their sweeps are bound by the length of the march: shorter chunks until
+  // the blocks fill the compute units about twice (measured: 256^3 best at 16 planes, 128^3 and below at 4)
+  while (ZC > 4 && per_chunk * ((g.n3 + ZC - 1) / ZC) < 400) ZC = (ZC + 1) / 2;
   if (mgx_fused_zc > 0) ZC = std::min(mgx_fused_zc, g.n3);
   pl.ZC = ZC;
   pl.nzc = (g.n3 + ZC - 1) / ZC;
@@ -631,7 +634,7 @@ static int mgx_fused_make_plan(MgxFusedPlan &pl, const MgxGeom &g, const std::ve
   for (int sel = 0; sel < 3; ++sel) {
     std::vector<int> fast, consto, boxed;   // no box in reach / only rho = 1 boxes / some box with rho != 1
     for (int tz = 0; tz < pl.nzc; ++tz) {
-      const bool edge = tz == 0 || tz == pl.nzc - 1;
+      const bool edge = 1 + tz * ZC <= 2 || std::min((tz + 1) * ZC, g.n3) >= g.n3 - 1;   // holds plane 1, 2, n3-1 or n3
       if ((sel == 1 && !edge) || (sel == 2 && edge)) continue;
       for (int ty = 0; ty < pl.nty; ++ty)
         for (int tx = 0; tx < pl.ntx; ++tx) {
