@@ -1,0 +1,133 @@
+"""GPU: shapes and box tables the golden vectors do not reach — levels of one to a few cells, levels spanning several
+tiles in x and y and several z chunks, overlapping boxes, several boxes with rho != 1 (cells that see two of them take
+the six-division path, a third one has no weight table), constant boxes inside rho boxes, more boxes than the fused
+kernel's bit sets hold, values beyond the fast range of the exact sum — all against the oracle's red-black sweep,
+bit for bit, both kernels, both precisions; and the error codes of the entry points."""
+import numpy as np
+import pytest
+
+from oracle import oracle as orc
+from tests.helpers import bits_equal
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from multigrid_amd import lib
+    c = lib.Context(0)
+    yield c
+    c.close()
+
+
+def random_boxes(rng, n, nbox, rhos=(1.0, 3.0, 0.25, 7.5)):
+    boxes = []
+    for _ in range(nbox):
+        lo = [int(rng.integers(1, max(2, d))) for d in n]
+        hi = [int(min(d, l + rng.integers(0, max(1, d // 2) + 1))) for d, l in zip(n, lo)]
+        constant = bool(rng.integers(0, 3) == 0)
+        rho = 1.0 if constant else float(rng.choice(rhos))
+        boxes.append(orc.Box((lo[0], hi[0], lo[1], hi[1], lo[2], hi[2]), float(rng.uniform(-1, 1)), rho, constant))
+    return boxes
+
+
+def run_case(ctx, n, dtype, boxes, bc, sor, kernel, sweeps=3, seed=0, scale=1.0, a=(0.3, 0.3, 0.4)):
+    from multigrid_amd import lib
+    L = orc.Level(n=tuple(n), bc=tuple(bc), sor=sor, a=a, boxes=boxes)
+    rng = np.random.default_rng(seed)
+    V = (rng.standard_normal(L.shape()) * scale).astype(dtype)
+    orc.setup(L, V, False)
+    ctx.set_kernel(kernel)
+    lv = ctx.level(1, n, dtype)
+    try:
+        lv.set_params(sor, a, bc)
+        lv.set_boxes([b.place for b in boxes], [b.val for b in boxes], [b.rho for b in boxes], [int(b.constant) for b in boxes])
+        lv.upload(V)
+        lv.setup(False)
+        assert lv.count_nonconst() == orc.count_nonconst(L)
+        for k in range(sweeps):
+            red = (3, 1, 2, 0)[k % 4]
+            e2 = orc.sweep(L, V, orc.ORDER_RB)
+            s, big = orc.abs_sum_exact(L, V)
+            lv.sweep(1, red)
+            de2, ds, dbig = lv.result() if red else (None, None, None)
+            W = lv.download()
+            assert bits_equal(W, V), f"n={n} sweep {k}: max diff {np.abs(W.astype(np.float64) - V).max()}"
+            if red & 1:
+                assert de2 == e2
+            if red & 2:
+                assert dbig == big and ds == s
+    finally:
+        lv.close()
+        ctx.set_kernel(0)
+
+
+@pytest.mark.parametrize("kernel", [1, 2])
+@pytest.mark.parametrize("n", [(1, 1, 1), (2, 1, 3), (3, 3, 3), (5, 2, 7), (1, 9, 4), (17, 1, 1)])
+def test_tiny_levels(ctx, n, kernel):
+    rng = np.random.default_rng(sum(n))
+    for dtype in (np.float64, np.float32):
+        run_case(ctx, n, dtype, random_boxes(rng, n, 2), (1, 3, 2, 1, 3, 2), 1.5, kernel, seed=sum(n))
+
+
+@pytest.mark.parametrize("kernel", [1, 2])
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_random_boxes_across_tiles(ctx, seed, dtype, kernel):
+    """several tiles in x (n1 > 128) and y, several z chunks; up to nine overlapping boxes with four rho values"""
+    rng = np.random.default_rng(seed)
+    n = [(300, 70, 40), (140, 45, 75), (260, 23, 19)][seed - 1]
+    run_case(ctx, n, dtype, random_boxes(rng, n, 3 * seed), (1, 1, 2, 3, 3, 2), 1.6, kernel, seed=seed)
+
+
+@pytest.mark.parametrize("kernel", [1, 2])
+def test_nested_and_adjacent_rho_boxes(ctx, kernel):
+    """three boxes with rho != 1 touching each other and a constant box inside one of them"""
+    n = (150, 44, 36)
+    boxes = [orc.Box((20, 70, 5, 30, 4, 20), 0.0, 3.0, False), orc.Box((71, 120, 5, 30, 4, 20), 0.0, 0.5, False),
+             orc.Box((40, 100, 10, 40, 21, 30), 0.0, 9.0, False), orc.Box((30, 50, 10, 20, 8, 12), 0.75, 1.0, True),
+             orc.Box((60, 90, 1, 44, 1, 3), -0.5, 1.0, True)]
+    for dtype in (np.float64, np.float32):
+        run_case(ctx, n, dtype, boxes, (2, 2, 3, 3, 1, 1), 1.7, kernel, sweeps=4, seed=9)
+
+
+def test_more_boxes_than_bit_sets(ctx):
+    """40 boxes: the automatic choice falls back to the two-pass kernel; forcing the fused one is an error"""
+    from multigrid_amd import lib
+    n = (40, 30, 20)
+    rng = np.random.default_rng(40)
+    boxes = random_boxes(rng, n, 40)
+    run_case(ctx, n, np.float64, boxes, (1, 1, 2, 2, 3, 3), 1.5, 0, seed=40)
+    with pytest.raises(lib.MgxError):
+        run_case(ctx, n, np.float64, boxes, (1, 1, 2, 2, 3, 3), 1.5, 2, seed=40)
+
+
+@pytest.mark.parametrize("kernel", [1, 2])
+def test_sum_beyond_the_fast_range(ctx, kernel):
+    """|V| up to ~1e5: the two-double partial sums hand over to the integer path, same exact sum"""
+    n = (140, 24, 10)
+    run_case(ctx, n, np.float64, [], (1, 1, 1, 1, 1, 1), 1.2, kernel, seed=3, scale=3.0e4)
+
+
+def test_error_codes(ctx):
+    from multigrid_amd import lib
+    with pytest.raises(lib.MgxError) as e:
+        ctx.level(1, (0, 4, 4), np.float64)
+    assert e.value.code == -1
+    lv = ctx.level(1, (8, 8, 8), np.float64)
+    try:
+        with pytest.raises(lib.MgxError) as e:
+            lv.sweep(1, 0)                      # no parameters yet
+        assert e.value.code == -4
+        lv.set_params(1.5, (1 / 3,) * 3, (2,) * 6)
+        with pytest.raises(lib.MgxError) as e:
+            lv.set_boxes([(1, 2, 1, 2, 1, 2)], [0.0], [-1.0], [0])     # rho < 0 (t_mg.f90:352)
+        assert e.value.code == -1
+        with pytest.raises(lib.MgxError):
+            lv.half_sweep(2, 1, 8, 0)
+        with pytest.raises(lib.MgxError):
+            lv.sweep_part(lib.PART_INNER, 0)    # inner part without its edge part
+        with pytest.raises(lib.MgxError):
+            lv.plane_ptr(11, 1)
+    finally:
+        lv.close()
