@@ -91,6 +91,7 @@ struct MgxTransferPlan {
   int *d_tab = nullptr;         // restriction: mx | my | mz (forward maps); prolongation: rx | ry | rz as (lo, hi) pairs
   size_t off_y = 0, off_z = 0;  // element offsets of the y and z tables inside d_tab
   int cz_lo = 0, cz_hi = -1;    // prolongation: global child planes that feed this (slab of the) parent
+  bool halved = false;          // restriction: undivided levels, every child index c reads parent index 2c
 };
 
 static inline mgx_ctx *C(mgx_level *lv) { return lv->ctx; }
@@ -707,6 +708,11 @@ static int transfer_plan(const char *who, bool restrict_, mgx_level *src, mgx_le
   t->restrict_ = restrict_;
   std::vector<int> tab;
   if (restrict_) {
+    bool hv = gs.n3 == gs.n3g && gd.n3 == gd.n3g && gs.z0 == 0 && gd.z0 == 0;
+    for (int c = 1; c <= gd.n1 && hv; ++c) hv = mx[c] == 2 * c;
+    for (int c = 1; c <= gd.n2 && hv; ++c) hv = my[c] == 2 * c;
+    for (int c = 1; c <= gd.n3g && hv; ++c) hv = mz[c] == 2 * c;
+    t->halved = hv;
     tab = mx;
     t->off_y = tab.size(); tab.insert(tab.end(), my.begin(), my.end());
     t->off_z = tab.size(); tab.insert(tab.end(), mz.begin(), mz.end());
@@ -742,6 +748,14 @@ static int launch_restrict(bool half, mgx_level *src, mgx_level *dst, const MgxT
   const T *s = (const T *)src->buf[src->cur];
   T *d = (T *)dst->buf[dst->cur];
   const int *mx = t->d_tab, *my = t->d_tab + t->off_y, *mz = t->d_tab + t->off_z;
+  if (t->halved) {
+    constexpr int ZCH = 16;       // child planes one thread marches
+    dim3 g2((gd.n1 + 63) / 64, (gd.n2 + 3) / 4, (gd.n3 + ZCH - 1) / ZCH);
+    if (half) hipLaunchKernelGGL((k_restrict_halved<T, true, ZCH>), g2, dim3(256), 0, st, s, src->g, d, gd);
+    else hipLaunchKernelGGL((k_restrict_halved<T, false, ZCH>), g2, dim3(256), 0, st, s, src->g, d, gd);
+    HIP_TRY(hipGetLastError());
+    return MGX_OK;
+  }
   if (half) hipLaunchKernelGGL((k_transfer<T, true, true>), grid, dim3(256), 0, st, s, src->g, d, gd, mx, my, mz);
   else hipLaunchKernelGGL((k_transfer<T, false, true>), grid, dim3(256), 0, st, s, src->g, d, gd, mx, my, mz);
   HIP_TRY(hipGetLastError());

@@ -298,6 +298,10 @@ __global__ __launch_bounds__(256) void k_copy_shell(const T *__restrict__ src, T
   }
 }
 
+template <typename T> struct MgxPair;
+template <> struct MgxPair<double> { typedef double2 type; };
+template <> struct MgxPair<float> { typedef float2 type; };
+
 // ------------------------------------------------------------------------------------------------
 // transfer operators.  Index maps (g2g, t_mg_interp.f90:995-999, and the loop structure of each
 // operator) are built on the host exactly as the reference's loops run and passed as tables:
@@ -479,6 +483,87 @@ __global__ __launch_bounds__(256) void k_prolong(const T *__restrict__ src, cons
             for (int px = xr.x; px <= xr.y; ++px) row[px] = v;
           }
         }
+    }
+  }
+}
+
+// the restriction stencil from three 3x3 plane patches q[(dy+1)*3 + (dx+1)], in the reference's order
+// (t_mg_interp.f90:166-198; half :257-279)
+template <typename T, bool HALF>
+__device__ inline T mgx_restrict_from_planes(const T (&zm)[9], const T (&z0)[9], const T (&zp)[9]) {
+  const T den = HALF ? (T)56 : (T)64;
+  const T f4 = (T)1 / den, f3 = (T)2 / den, f2 = (T)4 / den, f1 = (T)8 / den;
+#define Q(a, dx, dy) a[((dy) + 1) * 3 + (dx) + 1]
+  T vt;
+  if (!HALF) {
+    vt = Q(zm, -1, -1) * f4;
+    vt = vt + Q(zp, -1, -1) * f4;
+    vt = vt + Q(zm, -1, +1) * f4;
+    vt = vt + Q(zp, -1, +1) * f4;
+    vt = vt + Q(zm, +1, -1) * f4;
+    vt = vt + Q(zp, +1, -1) * f4;
+    vt = vt + Q(zm, +1, +1) * f4;
+    vt = vt + Q(zp, +1, +1) * f4;
+    vt = vt + Q(z0, -1, -1) * f3;
+  } else {
+    vt = Q(z0, -1, -1) * f3;
+  }
+  vt = vt + Q(z0, -1, +1) * f3;
+  vt = vt + Q(zm, -1, 0) * f3;
+  vt = vt + Q(zp, -1, 0) * f3;
+  vt = vt + Q(z0, +1, -1) * f3;
+  vt = vt + Q(z0, +1, +1) * f3;
+  vt = vt + Q(zm, +1, 0) * f3;
+  vt = vt + Q(zp, +1, 0) * f3;
+  vt = vt + Q(zm, 0, -1) * f3;
+  vt = vt + Q(zp, 0, -1) * f3;
+  vt = vt + Q(zm, 0, +1) * f3;
+  vt = vt + Q(zp, 0, +1) * f3;
+  vt = vt + Q(z0, -1, 0) * f2;
+  vt = vt + Q(z0, +1, 0) * f2;
+  vt = vt + Q(z0, 0, -1) * f2;
+  vt = vt + Q(z0, 0, +1) * f2;
+  vt = vt + Q(zm, 0, 0) * f2;
+  vt = vt + Q(zp, 0, 0) * f2;
+  vt = vt + Q(z0, 0, 0) * f1;
+#undef Q
+  return vt;
+}
+
+// Restriction between undivided levels whose three dimensions were halved exactly: child cell (cx, cy, cz) takes the
+// stencil around parent cell (2cx, 2cy, 2cz) (t_mg_interp.f90:153-161 with g2g(n, 2c, n/2) = c; :244-252).  One thread
+// marches ZCH child planes of one child column and keeps the 3x3 patches of three parent planes in registers: the
+// patch of plane 2cz+1 serves child cz and child cz+1, and a patch row is one aligned 16-byte pair (2cx-1, 2cx)
+// plus the cell 2cx+1.
+template <typename T, bool HALF, int ZCH>
+__global__ __launch_bounds__(256) void k_restrict_halved(const T *__restrict__ src, const MgxGeom gs, T *__restrict__ dst,
+                                                         const MgxGeom gd) {
+  typedef typename MgxPair<T>::type V2;
+  const int cx = blockIdx.x * 64 + (threadIdx.x & 63) + 1;
+  const int cy = blockIdx.y * 4 + (threadIdx.x >> 6) + 1;
+  const int cbeg = 1 + blockIdx.z * ZCH, cend = min(cbeg + ZCH - 1, gd.n3);
+  if (cx > gd.n1 || cy > gd.n2) return;
+  const long long sy = gs.px;
+  T W[3][9];
+  auto fetch = [&](T (&q)[9], const int pz) {
+    const T *c = src + gs.idx(2 * cx - 1, 2 * cy, pz);
+#pragma unroll
+    for (int dy = -1; dy <= 1; ++dy) {
+      const V2 pr = *reinterpret_cast<const V2 *>(c + sy * dy);
+      q[(dy + 1) * 3 + 0] = pr.x;
+      q[(dy + 1) * 3 + 1] = pr.y;
+      q[(dy + 1) * 3 + 2] = c[2 + sy * dy];
+    }
+  };
+  fetch(W[0], 2 * cbeg - 1);
+  for (int cb = cbeg; cb <= cend; cb += 3) {
+#pragma unroll
+    for (int u = 0; u < 3; ++u) {
+      const int cz = cb + u;
+      if (cz > cend) break;
+      fetch(W[(2 * u + 1) % 3], 2 * cz);
+      fetch(W[(2 * u + 2) % 3], 2 * cz + 1);
+      dst[gd.idx(cx, cy, cz)] = mgx_restrict_from_planes<T, HALF>(W[(2 * u) % 3], W[(2 * u + 1) % 3], W[(2 * u + 2) % 3]);
     }
   }
 }
