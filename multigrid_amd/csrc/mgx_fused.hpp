@@ -495,7 +495,13 @@ __device__ __forceinline__ void mgx_fused_body(const T *__restrict__ src, T *__r
           vold[j] = vc;
           rnew[j] = actv[j] ? vv : vc;
           MGX_SET_RED(SM, u + 1, j, rnew[j])
-          if (st[j]) *reinterpret_cast<V2 *>(pb + gob[j]) = W[SM][j];     // the finished pair, as it sits in memory
+          if (st[j]) {            // the finished pair, as it sits in memory; streamed past the caches, which the
+            typedef T nv2 __attribute__((ext_vector_type(2)));   // halo rows of neighbouring tiles need more
+            nv2 o_;
+            o_.x = W[SM][j].x;
+            o_.y = W[SM][j].y;
+            __builtin_nontemporal_store(o_, reinterpret_cast<nv2 *>(pb + gob[j]));
+          }
         }
         if (reduce) {
 #pragma unroll

@@ -478,7 +478,7 @@ __global__ __launch_bounds__(256) void k_prolong(const T *__restrict__ src, cons
         for (int py = yr.x; py <= yr.y; ++py) {
           T *row = dst + gd.idx(0, py, pz);
           if (two) {
-            *reinterpret_cast<pair_t *>(row + xr.x) = vv;
+            __builtin_nontemporal_store(vv, reinterpret_cast<pair_t *>(row + xr.x));   // written once, not read here
           } else {
             for (int px = xr.x; px <= xr.y; ++px) row[px] = v;
           }
