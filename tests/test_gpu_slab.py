@@ -95,3 +95,70 @@ def test_slab_two_pass_kernel_refused():
     with pytest.raises(lib.MgxError):
         lv.sweep(1, 0)
     ctx.close()
+
+
+@pytest.mark.parametrize("method", [1, 2])
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+def test_slab_transfers_equal_undivided(dtype, method):
+    """restriction and prolongation between z slabs (aligned: every parent slab is twice its child slab) against the
+    undivided levels: the halo planes the stencils reach are the neighbours' boundary planes, copied beforehand"""
+    import torch
+    from multigrid_amd import lib, slab
+    nP, nC = (64, 40, 48), (32, 20, 24)
+    bc = (1, 1, 3, 2, 2, 3)
+    partsP, partsC = [(0, 20), (20, 28)], [(0, 10), (10, 14)]
+    none = (np.zeros((0, 6), np.int32), [], [], [])
+    boxP = (np.array([[10, 40, 5, 30, 1, 3]], dtype=np.int32), [0.5], [1.0], [1])
+    boxC = (np.array([[5, 20, 3, 15, 1, 2]], dtype=np.int32), [0.5], [1.0], [1])
+    ctx = lib.Context(0, None)
+
+    def mk(n, parts, layer, boxes):
+        out = []
+        for z0, k in parts:
+            lv = ctx.level(layer, n, dtype, z0, k)
+            lv.set_params(1.5, (1 / 3,) * 3, bc)
+            lv.set_boxes(*boxes)
+            out.append(lv)
+        return out
+
+    P, C_ = mk(nP, [(0, nP[2])], 1, boxP)[0], mk(nC, [(0, nC[2])], 2, boxC)[0]
+    Ps, Cs = mk(nP, partsP, 1, boxP), mk(nC, partsC, 2, boxC)
+
+    def exchange(slabs):
+        ctx.sync()
+        for lo, up in zip(slabs[:-1], slabs[1:]):
+            slab.device_plane_tensor(up, -1, 2).copy_(slab.device_plane_tensor(lo, lo.n3_local - 1, 2))
+            slab.device_plane_tensor(lo, lo.n3_local + 1, 2).copy_(slab.device_plane_tensor(up, 1, 2))
+        torch.cuda.synchronize()
+        for lv in slabs:
+            lv.halo_written()
+
+    rng = np.random.default_rng(3)
+    V0 = rng.standard_normal((nP[2] + 2, nP[1] + 2, nP[0] + 2)).astype(dtype)
+    P.upload(V0)
+    P.setup(False)
+    for lv, (z0, k) in zip(Ps, partsP):
+        lv.upload(np.ascontiguousarray(V0[z0:z0 + k + 2]))
+        lv.setup(False)
+    exchange(Ps)
+    # restriction
+    C_.bring_back()
+    lib.restrict(P, C_, method)
+    Wc = C_.download()
+    for lv, pl in zip(Cs, Ps):
+        lv.bring_back()
+        lib.restrict(pl, lv, method)
+    exchange(Cs)
+    for lv, (z0, k) in zip(Cs, partsC):
+        got = lv.download()
+        assert np.array_equal(got.view(np.uint8), Wc[z0:z0 + k + 2].view(np.uint8)), f"restriction, child slab z0={z0}"
+    # prolongation back (the parent is overwritten)
+    lib.prolong(C_, P, method)
+    Wp = P.download()
+    for lv, cl in zip(Ps, Cs):
+        lib.prolong(cl, lv, method)
+    exchange(Ps)
+    for lv, (z0, k) in zip(Ps, partsP):
+        got = lv.download()
+        assert np.array_equal(got.view(np.uint8), Wp[z0:z0 + k + 2].view(np.uint8)), f"prolongation, parent slab z0={z0}"
+    ctx.close()
