@@ -40,9 +40,13 @@ class Solver:
             self.attach(g)
 
     # -- device residency -------------------------------------------------------------------------
+    def make_level(self, g: G.MgGrid):
+        """the resident level behind g (a subclass may hand out a slab of it)"""
+        return self.ctx.level(g.layer, [int(v) for v in g.n], g.dtype)
+
     def attach(self, g: G.MgGrid):
         if g.dev is None:
-            g.dev = self.ctx.level(g.layer, [int(v) for v in g.n], g.dtype)
+            g.dev = self.make_level(g)
         self.push_params(g)
 
     def push_params(self, g: G.MgGrid):
@@ -70,6 +74,12 @@ class Solver:
 
     def setup(self, g, init: bool):        # grid_setup, t_mg.f90:465-588
         g.dev.setup(init)
+
+    def restriction(self, g):              # grid_restriction, t_mg_interp.f90:9-21 (into g.child)
+        lib.restrict(g.dev, g.child.dev, g.RES_method)
+
+    def prolongation(self, g):             # grid_prolongation, t_mg_interp.f90:23-35 (into g.parent)
+        lib.prolong(g.dev, g.parent.dev, g.PRO_method)
 
     def grid_sum(self, g) -> float:        # grid_sum, t_mg.f90:794-814 → real(grid_p)
         return self.t(g.dev.abs_sum())
@@ -132,7 +142,7 @@ class Solver:
             self.say(f"Completed ({grid.layer}) cycle in {grid.itt - old_itt} cycles")
             if grid.parent is not None:
                 self.bring_back(grid.parent)
-                lib.prolong(grid.dev, grid.parent.dev, grid.PRO_method)
+                self.prolongation(grid)
                 self.hold_back(grid)
             grid = grid.parent
 
@@ -177,7 +187,7 @@ class Solver:
                 break
             self._leg(grid)
             self.bring_back(grid.child)
-            lib.restrict(grid.dev, grid.child.dev, grid.RES_method)
+            self.restriction(grid)
             self.hold_back(grid)
             grid = grid.child
         while True:
@@ -187,7 +197,7 @@ class Solver:
                 return s_end if grid.steps > 0 else None
             if grid.parent is not None:
                 self.bring_back(grid.parent)
-                lib.prolong(grid.dev, grid.parent.dev, grid.PRO_method)
+                self.prolongation(grid)
                 self.hold_back(grid)
             grid = grid.parent
 
@@ -203,7 +213,7 @@ class Solver:
             if not pg.child.child.enabled:
                 break
             self.bring_back(pg.child)
-            lib.restrict(pg.dev, pg.child.dev, pg.RES_method)
+            self.restriction(pg)
             self.hold_back(pg)
             pg = pg.child
             cg = pg.child
@@ -234,7 +244,7 @@ class Solver:
                     alias_itol = True
             if pg.parent is not None:
                 self.bring_back(pg.parent)
-                lib.prolong(pg.dev, pg.parent.dev, pg.PRO_method)
+                self.prolongation(pg)
                 self.hold_back(pg)
                 cg = pg
                 pg = pg.parent

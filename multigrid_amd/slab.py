@@ -86,8 +86,26 @@ class SlabLevel:
     def planes(self, z: int, count: int):
         return self._plane_tensor(self.lv, z, count)
 
+    def _stream_ordered(self) -> bool:
+        """RCCL orders its transfers after the kernels enqueued on the current stream.  gloo (tests) reads the planes
+        from the host as soon as a send is posted, so a device level has to be idle before one is."""
+        ans = getattr(self, "_ordered", None)
+        if ans is None:
+            ctx = getattr(self.lv, "ctx", None)
+            ans = ctx is None or self.world == 1 or self.dist.get_backend(self.group) != "gloo"
+            self._ordered = ans
+        return ans
+
+    def _scalar_device(self):
+        """where the few numbers of a reduction live: the GPU for RCCL, the host for gloo"""
+        if self.dist.get_backend(self.group) == "gloo":
+            return "cpu"
+        return self.planes(1, 1).device
+
     def _run(self, ops):
         if ops:
+            if not self._stream_ordered():
+                self.lv.ctx.sync()
             for w in self.dist.batch_isend_irecv(ops):
                 w.wait()
 
@@ -99,6 +117,8 @@ class SlabLevel:
     def _start_exchange(self):
         if self.world == 1:
             return []
+        if not self._stream_ordered():
+            self.lv.ctx.sync()
         P, d, ops = self.dist.P2POp, self.dist, []
         # every rank lists its ops lower-neighbour first: matching order on both sides of a link
         if self.lower is not None:
@@ -162,7 +182,7 @@ class SlabLevel:
         if self.world == 1:
             return e2, s, units
         import torch
-        dev = self.planes(1, 1).device
+        dev = self._scalar_device()
         bad = 1.0 if (s != s) else 0.0
         mx = torch.tensor([e2, bad], dtype=torch.float64, device=dev)
         self.dist.all_reduce(mx, op=self.dist.ReduceOp.MAX, group=self.group)
@@ -174,3 +194,130 @@ class SlabLevel:
 
     def download(self) -> np.ndarray:
         return self.lv.download()
+
+
+# ----------------------------------------------------------------------------------------------------
+# the whole hierarchy over z slabs: the reference's cycle control (cycle.Solver) with every level decomposed
+
+def aligned_splits(levels: List[G.MgGrid], world: int) -> List[List[Tuple[int, int]]]:
+    """(z0, n3_local) per rank for every level, coarsest level split evenly and every finer slab the exact
+    pre-image of its child slab, so that restriction and prolongation reach at most the halo planes: a level
+    whose depth was halved doubles the slab, one whose depth was kept (t_mg.f90:191-194) keeps it."""
+    out = [split_planes(int(levels[-1].n[2]), world)]
+    for fine, coarse in zip(reversed(levels[:-1]), reversed(levels[1:])):
+        nf, nc = int(fine.n[2]), int(coarse.n[2])
+        if nf == 2 * nc:
+            out.append([(2 * z0, 2 * k) for z0, k in out[-1]])
+        elif nf == nc:
+            out.append(list(out[-1]))
+        else:
+            raise ValueError(f"levels of depth {nf} and {nc}: z slabs need a depth that is halved exactly or kept")
+    out.reverse()
+    if world > 1 and min(k for _, k in out[-1]) < 2:
+        raise ValueError(f"coarsest level of depth {int(levels[-1].n[2])} over {world} ranks: every slab needs at least 2 planes")
+    return out
+
+
+class SlabDevice(SlabLevel):
+    """a slab with the interface cycle.Solver expects of a resident level (multigrid_amd.lib.DeviceLevel)"""
+
+    def __init__(self, ctx, g: G.MgGrid, rank: int, world: int, z0: int, n3: int, group=None,
+                 level_factory: Optional[Callable] = None, plane_tensor: Optional[Callable] = None, overlap: bool = True):
+        import torch.distributed as dist
+        self.dist = dist
+        self.rank, self.world, self.group = int(rank), int(world), group
+        self.grid = g
+        self.z0, self.n3 = int(z0), int(n3)
+        self.n_global = tuple(int(v) for v in g.n)
+        make = level_factory if level_factory is not None else ctx.level
+        self.lv = make(g.layer, list(self.n_global), g.dtype, self.z0, self.n3)
+        self._plane_tensor = plane_tensor if plane_tensor is not None else device_plane_tensor
+        self.lower = rank - 1 if rank > 0 else None
+        self.upper = rank + 1 if rank < world - 1 else None
+        self.periodic_z = False
+        self.reduce = lib.RED_ERR | lib.RED_SUM
+        self.overlap = overlap and hasattr(self.lv, "sweep_part")
+
+    # parameters come through cycle.Solver.push_params
+    def set_params(self, sor, a, bc):
+        self.lv.set_params(sor, a, bc)
+        self.periodic_z = bc[4] == lib.BC_PERIODIC or bc[5] == lib.BC_PERIODIC
+
+    def set_boxes(self, *table):
+        self.lv.set_boxes(*table)
+
+    def bring_back(self):
+        self.lv.bring_back()
+
+    def release(self):
+        self.lv.release()
+
+    def close(self):
+        self.lv.close()
+
+    def count_nonconst(self) -> int:
+        return self.lv.count_nonconst()          # the library counts over the global level
+
+    def refresh_halos(self):
+        """after anything that rewrote the slab as a whole (set-up, restriction, prolongation)"""
+        if self.periodic_z:
+            self._exchange_periodic_ghosts()
+        self.exchange_halos()
+        self.lv.halo_written()
+
+    def setup(self, init: bool):
+        self.lv.setup(init)
+        self.refresh_halos()
+
+    def sweep(self, nsweeps: int = 1, reduce: Optional[int] = None):     # `nsweeps` x gs_step
+        red = self.reduce if reduce is None else reduce
+        for s in range(int(nsweeps)):
+            SlabLevel.sweep(self, red if s == nsweeps - 1 else 0)
+
+    def abs_sum(self) -> float:
+        """grid_sum over the whole level: the slabs' exact integer sums added exactly"""
+        units = self.lv.abs_sum_limbs()
+        if self.world > 1:
+            import torch
+            dev = self._scalar_device()
+            digits = torch.tensor([(units >> (32 * i)) & 0xFFFFFFFF for i in range(4)], dtype=torch.int64, device=dev)
+            self.dist.all_reduce(digits, op=self.dist.ReduceOp.SUM, group=self.group)
+            units = sum(int(v) << (32 * i) for i, v in enumerate(digits.tolist()))
+        return units / SUM_UNITS
+
+
+class SlabSolver:
+    """mixin over cycle.Solver: every level is a SlabDevice; restriction and prolongation are local given current
+    halo planes (the slabs are aligned) and are followed by the halo refresh of the level they wrote"""
+
+    @staticmethod
+    def build(top: G.MgGrid, ctx, rank: int, world: int, group=None, level_factory=None, plane_tensor=None,
+              transfer=None, overlap: bool = True, **kw):
+        from . import cycle
+        levels = list(top.levels())
+        splits = aligned_splits(levels, world)
+        by_layer = {g.layer: sp[rank] for g, sp in zip(levels, splits)}
+        do_restrict, do_prolong = transfer if transfer is not None else (lib.restrict, lib.prolong)
+
+        class _Solver(cycle.Solver):
+            def make_level(self, g):
+                z0, n3 = by_layer[g.layer]
+                return SlabDevice(ctx, g, rank, world, z0, n3, group=group, level_factory=level_factory,
+                                  plane_tensor=plane_tensor, overlap=overlap)
+
+            def restriction(self, g):
+                do_restrict(g.dev.lv, g.child.dev.lv, g.RES_method)
+                g.child.dev.refresh_halos()
+
+            def prolongation(self, g):
+                do_prolong(g.dev.lv, g.parent.dev.lv, g.PRO_method)
+                g.parent.dev.refresh_halos()
+
+        return _Solver(top, ctx=ctx if ctx is not None else _NoContext(), **kw)
+
+
+class _NoContext:
+    """stands in for lib.Context when the levels come from a factory (tests)"""
+
+    def close(self):
+        pass

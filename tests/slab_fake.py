@@ -94,3 +94,77 @@ class FakeSlabLevel:
 
 def plane_tensor(lv: FakeSlabLevel, z: int, count: int):
     return torch.from_numpy(lv.V[z + 1:z + 1 + count])
+
+
+class FakeCycleLevel(FakeSlabLevel):
+    """the fake slab with the rest of the interface multigrid_amd.slab.SlabDevice forwards to.  Operators that look
+    at the level as a whole (set-up of existing values, restriction, prolongation) gather the slabs of all ranks,
+    apply the oracle to the undivided level and keep this rank's planes; planes that only the halo exchange may
+    supply are left stale on purpose, so a missing exchange shows up as a wrong result."""
+
+    def bring_back(self):
+        self.V[:] = 0
+
+    def release(self):
+        pass
+
+    def close(self):
+        pass
+
+    def count_nonconst(self):
+        return orc.count_nonconst(self._global_level())
+
+    def abs_sum_limbs(self):
+        n1, n2, _ = self.n_global
+        return orc.abs_sum_exact(orc.Level(n=(n1, n2, self.n3)), np.ascontiguousarray(self.V[1:self.n3 + 3]))[1]
+
+    def gather_global(self):
+        """the undivided level as every rank sees it: owned planes of all ranks + the two global ghost planes"""
+        import torch.distributed as dist
+        n1, n2, n3g = self.n_global
+        parts = [None] * dist.get_world_size()
+        dist.all_gather_object(parts, (self.z0, self.n3, self.V[1:self.n3 + 3].copy()))
+        Vg = np.zeros((n3g + 2, n2 + 2, n1 + 2), dtype=self.dtype)
+        for z0, n3, pl in parts:
+            Vg[z0 + 1:z0 + n3 + 1] = pl[1:-1]
+            if z0 == 0:
+                Vg[0] = pl[0]
+            if z0 + n3 == n3g:
+                Vg[n3g + 1] = pl[-1]
+        return Vg
+
+    def take_from_global(self, Vg):
+        """owned planes and global ghost planes; inner halos and periodic ghosts belong to the exchange"""
+        n3g = self.n_global[2]
+        whole = self.z0 == 0 and self.n3 == n3g
+        for lz in range(0, self.n3 + 2):
+            gz = lz + self.z0
+            inner_halo = (lz == 0 and self.z0 > 0) or (lz == self.n3 + 1 and self.z0 + self.n3 < n3g)
+            periodic_ghost = ((gz == 0 and self.bc[4] == 1) or (gz == n3g + 1 and self.bc[5] == 1)) and not whole
+            if not inner_halo and not periodic_ghost:
+                self.V[lz + 1] = Vg[gz]
+
+    def setup(self, init):
+        Vg = self.gather_global()
+        orc.setup(self._global_level(), Vg, bool(init))
+        self.take_from_global(Vg)
+
+    def sweep(self, nsweeps, reduce):
+        for _ in range(int(nsweeps)):
+            FakeSlabLevel.sweep(self, 1, reduce)
+
+
+def fake_restrict(parent: FakeCycleLevel, child: FakeCycleLevel, method: int):
+    P, Cl = parent._global_level(), child._global_level()
+    P.res_method = int(method)
+    Vp, Vc = parent.gather_global(), child.gather_global()
+    orc.restrict(P, Vp, Cl, Vc)
+    child.take_from_global(Vc)
+
+
+def fake_prolong(child: FakeCycleLevel, parent: FakeCycleLevel, method: int):
+    P, Cl = parent._global_level(), child._global_level()
+    Cl.pro_method = int(method)
+    Vp, Vc = parent.gather_global(), child.gather_global()
+    orc.prolong(Cl, Vc, P, Vp)
+    parent.take_from_global(Vp)
