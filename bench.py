@@ -138,6 +138,8 @@ def main():
     ap.add_argument("--kernel", type=int, default=0, help="0 auto, 1 two-pass, 2 fused")
     ap.add_argument("--own-stream", action="store_true", help="let the library create its stream (events then see nothing)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for --gpus > 1 (nccl = RCCL)")
+    ap.add_argument("--dist-vcycle", action="store_true",
+                    help="with --gpus > 1: also time the complete v-cycle solve with every level decomposed into z slabs")
     ap.add_argument("--no-overlap", action="store_true", help="exchange the halo planes after the whole sweep")
     args = ap.parse_args()
 
@@ -252,6 +254,27 @@ def main():
         torch.cuda.synchronize()
         tv = time.perf_counter() - tv0
         h = solver.history_array()
+        out["vcycle"] = {"seconds": tv, "status": status, "tol": float(args.vcycle_tol),
+                         "sweeps_per_level": [int(g.itt) for g in top.levels()],
+                         "levels": [[int(v) for v in g.n] for g in top.levels()],
+                         "final_err": float(h["err"][-1]) if len(h) else None,
+                         "lattice_updates": int(sum(int(g.itt) * int(np.prod(g.n)) for g in top.levels()))}
+    if world > 1 and args.dist_vcycle:
+        # the same solve with every level of the hierarchy as z slabs aligned between levels: transfers are local,
+        # each is followed by one halo refresh, reductions are all-reduced (exact sum: identical on every rank)
+        sl.lv.close()
+        dsolver = slab.SlabSolver.build(top, ctx, rank, world, overlap=not args.no_overlap, print_sums=False,
+                                        max_sweeps=200000)
+        barrier()
+        tv0 = time.perf_counter()
+        status = "converged"
+        try:
+            dsolver.mg_gs_cds(cycle.CDS_W_CYCLE)
+        except Exception as e:
+            status = f"stopped: {e}"
+        barrier()
+        tv = time.perf_counter() - tv0
+        h = dsolver.history_array()
         out["vcycle"] = {"seconds": tv, "status": status, "tol": float(args.vcycle_tol),
                          "sweeps_per_level": [int(g.itt) for g in top.levels()],
                          "levels": [[int(v) for v in g.n] for g in top.levels()],
