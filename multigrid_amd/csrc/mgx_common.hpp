@@ -88,6 +88,7 @@ __host__ __device__ inline void mgx_exact_add(u64 &lo, u64 &hi, double a, unsign
 // lo| < 2^-19: 53 bits above 2^-72); mgx_fast_sum_flush moves them into the 128-bit integer.  The build
 // keeps IEEE semantics (no contraction, no fast-math), so the compiler does not fold (a + c) - c.
 #define MGX_FAST_SUM_LIMIT 2048.0
+#define MGX_FAST_SUM_LIMIT_HI 0x40A00000u        /* high word of 2048.0: |v| >= 2048 or not finite <=> high word of |v| >= this */
 #define MGX_FAST_SUM_CELLS 1023
 
 __device__ inline void mgx_fast_sum_add(double &h, double &l, const double a) {

@@ -168,6 +168,10 @@ __device__ inline T mgx_cell_from_code(const unsigned code, const T vc, const T 
   return p.s1 * vc + p.s2 * avg;
 }
 
+// max(m, |d|) in one instruction (a NaN difference is ignored, as by `|d| > m ? |d| : m`)
+__device__ __forceinline__ double mgx_max_abs(double m, double d) { return __builtin_fmax(m, __builtin_fabs(d)); }
+__device__ __forceinline__ float mgx_max_abs(float m, float d) { return __builtin_fmaxf(m, __builtin_fabsf(d)); }
+
 // branch-free form of mgx_exact_add (same integer result)
 __device__ inline void mgx_exact_add_nb(u64 &lo, u64 &hi, double a, unsigned &ovf) {
   const u64 bits = (u64)__double_as_longlong(a) & 0x7FFFFFFFFFFFFFFFull;
@@ -365,20 +369,33 @@ __device__ __forceinline__ void mgx_fused_body(const T *__restrict__ src, T *__r
   unsigned zmm = 0u;               // Z set of plane k-2
   static_assert(2 * RW * NSET <= MGX_FAST_SUM_CELLS, "partial sums must stay exact between two flushes");
   // |V| of R cells into the sum: two-double partial sums while every value is below the fast limit (the
-  // branch is uniform and practically never taken), the integer path otherwise
+  // branch is uniform and practically never taken), the integer path otherwise.  A cell that does not count
+  // gets the high word of |V| cleared: what is left is below 2^-1022 and adds exactly nothing to either
+  // partial sum, one 32-bit select instead of a 64-bit one; the limit test is one integer compare on the
+  // largest high word.
 #define MGX_SUM_R(val, cond)                                                           \
   {                                                                                    \
     double a_[R];                                                                      \
-    bool big_ = false;                                                                 \
+    unsigned top_ = 0u;                                                                \
     _Pragma("unroll") for (int j = 0; j < R; ++j) {                                    \
-      a_[j] = (cond) ? fabs((double)(val)) : 0.0;                                      \
-      big_ = big_ || !(a_[j] < MGX_FAST_SUM_LIMIT);                                    \
+      const double v_ = (double)(val);                                                 \
+      const unsigned h_ = (cond) ? ((unsigned)__double2hiint(v_) & 0x7fffffffu) : 0u;  \
+      a_[j] = __hiloint2double((int)h_, __double2loint(v_));                           \
+      top_ = h_ > top_ ? h_ : top_;                                                    \
     }                                                                                  \
-    if (__builtin_expect(__any(big_), 0)) {                                            \
-      _Pragma("unroll") for (int j = 0; j < R; ++j) mgx_exact_add_nb(slo, shi, a_[j], ovf); \
+    if (__builtin_expect(__any(top_ >= MGX_FAST_SUM_LIMIT_HI), 0)) {                   \
+      _Pragma("unroll") for (int j = 0; j < R; ++j)                                    \
+        mgx_exact_add_nb(slo, shi, (cond) ? a_[j] : 0.0, ovf);                         \
     } else {                                                                           \
       _Pragma("unroll") for (int j = 0; j < R; ++j) mgx_fast_sum_add(fh, fl2, a_[j]);  \
     }                                                                                  \
+  }
+  // rows of the tile proper (the grown ring belongs to the neighbouring tiles' reductions): uniform per wave
+  bool rowin[R];
+#pragma unroll
+  for (int j = 0; j < R; ++j) {
+    const int r_ = __builtin_amdgcn_readfirstlane(wave) + NW * j;
+    rowin[j] = !HALO && r_ >= 2 && r_ <= LR - 3;
   }
 
   for (int kb = zc0 - 1; kb <= zc1 + 1; kb += NSET) {
@@ -449,13 +466,12 @@ __device__ __forceinline__ void mgx_fused_body(const T *__restrict__ src, T *__r
 #pragma unroll
         for (int j = 0; j < R; ++j) L(sk, 0, li[j]) = cnew[j];
         if (!HALO && reduce) {    // halo pairs belong to the neighbouring tiles' reductions
+          // a cell that was not updated has cnew = vold: only the wave-uniform part of "owned" needs a test
 #pragma unroll
           for (int j = 0; j < R; ++j) {
-            const bool own = actv[j] && zown && (fl[j] & (MGX_Q(u, j) ? MGX_F_OWN1 : MGX_F_OWN0)) != 0;
-            actv[j] = own;
-            const T d = cnew[j] - vold[j];
-            const T ad = own ? (d < (T)0 ? -d : d) : (T)0;
-            err = ad > err ? ad : err;
+            const bool urow = zown && rowin[j];
+            actv[j] = actv[j] && urow;
+            if (urow) err = mgx_max_abs(err, cnew[j] - vold[j]);
           }
           if (reduce & 2) MGX_SUM_R(cnew[j], actv[j])
         }
@@ -505,11 +521,7 @@ __device__ __forceinline__ void mgx_fused_body(const T *__restrict__ src, T *__r
         }
         if (reduce) {
 #pragma unroll
-          for (int j = 0; j < R; ++j) {
-            const T d = rnew[j] - vold[j];
-            const T ad = actv[j] ? (d < (T)0 ? -d : d) : (T)0;
-            err = ad > err ? ad : err;
-          }
+          for (int j = 0; j < R; ++j) err = mgx_max_abs(err, rnew[j] - vold[j]);   // 0 where nothing was updated
           if (reduce & 2) MGX_SUM_R(rnew[j], actv[j])
         }
       }

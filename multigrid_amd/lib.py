@@ -7,6 +7,7 @@ from __future__ import annotations
 
 import ctypes as C
 import os
+import sys
 from typing import Optional, Sequence, Tuple
 
 import numpy as np
@@ -38,6 +39,9 @@ class MgxError(RuntimeError):
 
 
 _lib = None
+# PyTorch-ROCm ships a HIP runtime of its own.  A process that uses both must import torch before this library is
+# loaded, so that the library binds to torch's runtime; the other order leaves two runtimes, and torch finds no GPU.
+torch_loaded_first = False
 
 
 def load():
@@ -48,6 +52,8 @@ def load():
     if not os.path.exists(LIB_PATH):
         raise ImportError(f"{LIB_PATH} is missing: build it with `make -C multigrid_amd/csrc` "
                           "(or __graft_entry__.build()); multigrid_amd has no CPU fallback")
+    global torch_loaded_first
+    torch_loaded_first = "torch" in sys.modules
     L = C.CDLL(LIB_PATH)
     vp, i32, i64, dbl = C.c_void_p, C.c_int32, C.c_int64, C.c_double
     pi32, pdbl, pu64 = C.POINTER(i32), C.POINTER(dbl), C.POINTER(C.c_uint64)

@@ -51,6 +51,9 @@ class _DevicePlanes:
 
 
 def device_plane_tensor(lv: "lib.DeviceLevel", z: int, count: int):
+    if not lib.torch_loaded_first:
+        raise RuntimeError("import torch before the first multigrid_amd.lib.Context is created: the HIP library must "
+                           "bind to the HIP runtime PyTorch ships, or torch cannot see the planes")
     import torch
     ptr, nbytes = lv.plane_ptr(z, count)
     return torch.as_tensor(_DevicePlanes(ptr, nbytes), device=torch.device("cuda", lv.ctx.device))

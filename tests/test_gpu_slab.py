@@ -5,6 +5,7 @@ import sys
 
 import numpy as np
 import pytest
+import torch          # noqa: F401  before the HIP library: the process must end up with one HIP runtime, torch's
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
