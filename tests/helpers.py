@@ -45,3 +45,38 @@ def oracle_levels(top):
             boxes=[orc.Box(tuple(int(max(-2**31, min(2**31 - 1, v))) for v in b.place), float(b.val), float(b.rho),
                            bool(b.constant)) for b in g.box]))
     return out
+
+
+def config4_input(nx=40, nz=640, tol="1.e-3", tol_last="1.e-4", method="v-cycle"):
+    """the elongated multi-GPU configuration (256 x 256 x 4096 in full) scaled down: electrodes at the two z ends,
+    x and y stop halving while z goes on (t_mg.f90:191-194), `max-layers 4`, a per-layer block for the coarsest level"""
+    Lx, Lz = nx * 0.1, nz * 0.1
+    return f"""
+cell {Lx:.10g} {Lx:.10g} {Lz:.10g}
+max-layers 4
+boxes 4
+method {method}
+begin layers
+  sor 1.7
+  tol {tol}
+  v-steps 2
+  mesh-size {nx} {nx} {nz}
+  bc all periodic
+  bc c- neumann
+  bc c+ dirichlet
+  interp full
+end layers
+begin layer -1
+  tol {tol_last}
+end layer
+begin box
+  llc {0.25 * Lx:.10g} {0.25 * Lx:.10g} 0.
+  cell {0.5 * Lx:.10g} {0.5 * Lx:.10g} {0.05 * Lz:.10g}
+  value 0.5
+end box
+begin box
+  llc {0.25 * Lx:.10g} {0.25 * Lx:.10g} {0.95 * Lz:.10g}
+  cell {0.5 * Lx:.10g} {0.5 * Lx:.10g} {0.05 * Lz:.10g}
+  value -0.5
+end box
+"""

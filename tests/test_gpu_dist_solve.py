@@ -14,11 +14,13 @@ sys.path.insert(0, ROOT)
 
 from multigrid_amd import mgio                                   # noqa: E402
 from oracle import oracle as orc                                 # noqa: E402
-from tests.helpers import DT, load, oracle_levels                # noqa: E402
+from tests.helpers import DT, config4_input, load, oracle_levels  # noqa: E402
 
 pytestmark = pytest.mark.gpu
 
-CASES = [("solve_64_bu", "f64", None), ("solve_64x48x80_v_half", "f32", None), ("solve_80_v", "f64", ("sor 1.8", "sor 1.6"))]
+# the last case is the elongated multi-GPU configuration scaled down (x and y stop halving, four levels)
+CASES = [("solve_64_bu", "f64", None), ("solve_64x48x80_v_half", "f32", None), ("solve_80_v", "f64", ("sor 1.8", "sor 1.6")),
+         ("config4", "f64", None)]
 
 
 def _free_port():
@@ -31,7 +33,7 @@ def _free_port():
 
 @pytest.mark.parametrize("name,prec,sub", CASES)
 def test_two_rank_solve_matches_oracle(name, prec, sub, tmp_path):
-    text = str(load(f"{name}_{prec}")["input"])
+    text = config4_input() if name == "config4" else str(load(f"{name}_{prec}")["input"])
     if sub:
         assert sub[0] in text
         text = text.replace(*sub)

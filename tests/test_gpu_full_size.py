@@ -1,0 +1,138 @@
+"""GPU, at the size the benchmark is quoted on (512^3 fp64, mixed periodic / Neumann / Dirichlet, two plate electrodes and a
+rho = 3 block): set-up, red-black sweeps with both reductions, restriction to 256^3 and prolongation back, each against
+the oracle on the same data, bit for bit; the two sweep kernels against each other; two z slabs against the whole level."""
+import os
+import sys
+
+import numpy as np
+import pytest
+import torch          # noqa: F401  before the HIP library: one HIP runtime per process
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from oracle import oracle as orc                                  # noqa: E402
+from tests.helpers import bits_equal, oracle_levels               # noqa: E402
+
+pytestmark = pytest.mark.gpu
+
+N = 512
+
+
+@pytest.fixture(scope="module")
+def hierarchy():
+    from bench import config3_input
+    from multigrid_amd import mgio
+    return mgio.iomg_read(mgio.MgIO(text=config3_input((N, N, N))), dtype=np.float64)
+
+
+@pytest.fixture(scope="module")
+def ctx():
+    from multigrid_amd import lib
+    c = lib.Context(0)
+    yield c
+    c.close()
+
+
+def _device(ctx, g, z0=0, n3=None):
+    from multigrid_amd import grid as G
+    lv = ctx.level(g.layer, [int(v) for v in g.n], g.dtype, z0, n3)
+    lv.set_params(g.sor, [float(v) for v in g.a], g.bc6())
+    lv.set_boxes(*G.box_table(g))
+    return lv
+
+
+def test_sweeps_and_transfers_match_oracle(ctx, hierarchy):
+    from multigrid_amd import lib
+    top = hierarchy
+    child = top.child
+    assert [int(v) for v in top.n] == [N] * 3 and [int(v) for v in child.n] == [N // 2] * 3
+    Lp, Lc = oracle_levels(top)[:2]
+    V = np.zeros(Lp.shape(), dtype=np.float64)
+    orc.setup(Lp, V, True)
+    dp, dc = _device(ctx, top), _device(ctx, child)
+    try:
+        dp.bring_back()
+        dp.setup(True)
+        assert bits_equal(dp.download(), V)
+        assert dp.count_nonconst() == orc.count_nonconst(Lp)
+        for _ in range(2):
+            e2 = orc.sweep(Lp, V, orc.ORDER_RB)
+            s, units = orc.abs_sum_exact(Lp, V)
+            dp.sweep(1, lib.RED_ERR | lib.RED_SUM)
+            assert dp.result() == (e2, s, units)
+        assert bits_equal(dp.download(), V)
+        # restriction (grid_restriction_full + set-up of the child) and prolongation back
+        Vc = np.zeros(Lc.shape(), dtype=np.float64)
+        orc.restrict(Lp, V, Lc, Vc)
+        dc.bring_back()
+        lib.restrict(dp, dc, top.RES_method)
+        assert bits_equal(dc.download(), Vc)
+        orc.sweep(Lc, Vc, orc.ORDER_RB)
+        dc.sweep(1, 0)
+        Vp = np.zeros(Lp.shape(), dtype=np.float64)
+        orc.prolong(Lc, Vc, Lp, Vp)
+        dp.bring_back()
+        lib.prolong(dc, dp, child.PRO_method)
+        assert bits_equal(dp.download(), Vp)
+    finally:
+        dp.close()
+        dc.close()
+
+
+def test_two_kernels_and_two_slabs_agree(ctx, hierarchy):
+    """eight sweeps from the set-up state: fused kernel, two-pass kernel and a pair of z slabs (halo planes copied on
+    the device) must hold the same bits and report the same reductions"""
+    from multigrid_amd import lib, slab
+    top = hierarchy
+    whole = _device(ctx, top)
+    parts = [(0, 300), (300, 212)]
+    slabs = [_device(ctx, top, z0, k) for z0, k in parts]
+    try:
+        for lv in [whole] + slabs:
+            lv.bring_back()
+            lv.setup(True)
+
+        def exchange():
+            ctx.sync()
+            lo, up = slabs
+            slab.device_plane_tensor(up, -1, 2).copy_(slab.device_plane_tensor(lo, lo.n3_local - 1, 2))
+            slab.device_plane_tensor(lo, lo.n3_local + 1, 2).copy_(slab.device_plane_tensor(up, 1, 2))
+            torch.cuda.synchronize()
+            for lv in slabs:
+                lv.halo_written()
+
+        exchange()
+        res = {}
+        red = lib.RED_ERR | lib.RED_SUM
+        for it in range(8):
+            whole.sweep(1, red)
+            res[it] = whole.result()
+            parts_res = []
+            for lv in slabs:
+                lv.sweep(1, red)
+                parts_res.append(lv.result())
+            exchange()
+            assert max(r[0] for r in parts_res) == res[it][0]
+            assert sum(r[2] for r in parts_res) == res[it][2]
+        W = whole.download()
+        for lv, (z0, k) in zip(slabs, parts):
+            assert bits_equal(lv.download()[1:-1], W[z0 + 1:z0 + k + 1])
+        for lv in slabs:
+            lv.close()
+        slabs = []
+        # the same eight sweeps with the two-pass kernel
+        ctx.set_kernel(lib.KERNEL_TWO_PASS)
+        other = _device(ctx, top)
+        slabs = [other]
+        other.bring_back()
+        other.setup(True)
+        for it in range(8):
+            other.sweep(1, red)
+            assert other.result() == res[it]
+        assert bits_equal(other.download(), W)
+    finally:
+        ctx.set_kernel(0)
+        whole.close()
+        for lv in slabs:
+            lv.close()
