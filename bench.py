@@ -259,6 +259,22 @@ def main():
                          "levels": [[int(v) for v in g.n] for g in top.levels()],
                          "final_err": float(h["err"][-1]) if len(h) else None,
                          "lattice_updates": int(sum(int(g.itt) * int(np.prod(g.n)) for g in top.levels()))}
+    exe = os.path.join(ROOT, "multigrid_amd", "fortran", "mg_gpu_f64")
+    if world == 1 and not args.no_vcycle and os.path.exists(exe):
+        # the same solve driven by the Fortran host (the reference's cycle control over the C ABI, ISO_C_BINDING), as
+        # a child process with a context of its own
+        with tempfile.TemporaryDirectory() as td:
+            case = os.path.join(td, "case.txt")
+            mgio.write_host_case(top, cycle.CDS_W_CYCLE, case)
+            try:
+                r = subprocess.run([exe, case, "-", "noprint"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT,
+                                   universal_newlines=True, timeout=600)
+                sec = [float(l.split()[-1]) for l in r.stdout.splitlines() if l.startswith("mg_gpu: solve seconds")]
+                per = [[int(v) for v in l.split(":")[-1].split()] for l in r.stdout.splitlines() if "sweeps per level" in l]
+                out["vcycle_fortran_host"] = {"seconds": sec[0] if sec else None, "returncode": r.returncode,
+                                              "sweeps_per_level": per[0] if per else None}
+            except Exception as e:
+                out["vcycle_fortran_host"] = {"seconds": None, "error": str(e)}
     if world > 1 and args.dist_vcycle:
         # the same solve with every level of the hierarchy as z slabs aligned between levels: transfers are local,
         # each is followed by one halo refresh, reductions are all-reduced (exact sum: identical on every rank)

@@ -3,7 +3,10 @@
 ! solves it on the GPU with the reference's cycle control and writes the residual history, the sweep
 ! counts and the final top-level field to a binary file.
 !
-!   mg_gpu <case.txt> <out.bin>
+!   mg_gpu <case.txt> <out.bin | -> [noprint]
+!
+! `noprint` leaves out the sums gs_V evaluates only to print them (m_gs_CDS.F90:238,245,269,275).  The wall time
+! of the solve (hierarchy resident, first kernel to last result) is printed on the last line.
 !
 ! case.txt (list-directed):  nlevels method kernel
 !   per level:  n1 n2 n3 / sor / a1 a2 a3 / tol / steps / A0 A1 B0 B1 C0 C1 / restrict prolong / enabled / nbox
@@ -18,7 +21,8 @@ program mg_gpu
 
   type(host_grid), allocatable, target :: lv(:)
   real(grid_p), allocatable :: V(:,:,:)
-  character(len=1024) :: fcase, fout
+  character(len=1024) :: fcase, fout, opt
+  integer(c_int64_t) :: t0, t1, rate
   type(c_ptr) :: ctx
   integer :: nlev, method, kernel, i, j, u, en, cst, place(6)
   real(c_double) :: val, rho, sor, a(3), tol
@@ -26,6 +30,10 @@ program mg_gpu
   if ( command_argument_count() < 2 ) stop 'usage: mg_gpu <case.txt> <out.bin>'
   call get_command_argument(1, fcase)
   call get_command_argument(2, fout)
+  if ( command_argument_count() >= 3 ) then
+     call get_command_argument(3, opt)
+     if ( trim(opt) == 'noprint' ) print_sums = .false.
+  end if
 
   open(newunit=u, file=trim(fcase), status='old', action='read')
   read(u, *) nlev, method, kernel
@@ -63,8 +71,13 @@ program mg_gpu
   call mgx_check(mgx_ctx_create(0_c_int, c_null_ptr, ctx))
   call mgx_check(mgx_ctx_set_kernel(ctx, int(kernel, c_int)))
   call host_attach(ctx, lv(1))
+  call mgx_check(mgx_ctx_sync(ctx))
+  call system_clock(t0, rate)
   call mg_gs_cds(lv(1), method)
+  call mgx_check(mgx_ctx_sync(ctx))
+  call system_clock(t1)
 
+  if ( trim(fout) /= '-' ) then        ! `-`: timing run, nothing written
   allocate(V(0:lv(1)%n(1)+1, 0:lv(1)%n(2)+1, 0:lv(1)%n(3)+1))
   call host_download(lv(1), V)
 
@@ -79,12 +92,14 @@ program mg_gpu
   write(u) (int(lv(i)%itt, c_int32_t), i = 1, nlev)
   write(u) V
   close(u)
+  end if
 
   write(*,'(a,i0,a)', advance='no') 'mg_gpu: ', history%n, ' convergence tests; sweeps per level:'
   do i = 1 , nlev
      write(*,'(tr1,i0)', advance='no') lv(i)%itt
   end do
   write(*,*)
+  write(*,'(a,es14.6)') 'mg_gpu: solve seconds ', real(t1 - t0, c_double) / real(rate, c_double)
 
   call host_detach(lv(1))
   call mgx_check(mgx_ctx_destroy(ctx))
