@@ -90,9 +90,10 @@ class Solver:
     def tolerance(self, g) -> float:       # grid_tolerance, t_mg.f90:857-868
         return self.t(G.grid_tolerance(g))
 
-    def gs_steps(self, g, nsteps: int, want_sum: bool):
+    def gs_steps(self, g, nsteps: int, want_sum: bool, fetch: bool = True):
         """`nsteps` × gs_step (m_gs_CDS.F90:296-315); returns the grid_sum after the last one if asked.
-        grid%err = sqrt(max dV^2) of the last sweep."""
+        grid%err = sqrt(max dV^2) of the last sweep.  With fetch=False the sweeps are only enqueued: the level keeps
+        its result record until it is swept again, and grid%err is read from it when somebody asks (level_err)."""
         if nsteps <= 0:
             return self.grid_sum(g) if want_sum else None
         g.itt += nsteps
@@ -100,16 +101,28 @@ class Solver:
         if self.total_sweeps > self.max_sweeps:
             raise G.MgStop(f"more than {self.max_sweeps} sweeps")
         g.dev.sweep(nsteps, lib.RED_ERR | (lib.RED_SUM if want_sum else 0))
+        if not (fetch or want_sum):
+            g.err_pending = True
+            return None
         e2, s, _ = g.dev.result()
         g.err = float(np.sqrt(self.t(e2)))
+        g.err_pending = False
         if want_sum and s != s:
             # the reference would carry the overflowing sum through its `do while (tol > ...)` tests, which a NaN
             # ends as if converged (m_gs_CDS.F90:200-210); a diverging iteration is reported instead
             raise G.MgStop(f"layer {g.layer}: |V| reached 2^20 or is not finite after {g.itt} sweeps: the iteration diverges")
         return self.t(s) if want_sum else None
 
+    def level_err(self, g) -> float:
+        """grid%err, read back from the level if its last sweeps were only enqueued"""
+        if getattr(g, "err_pending", False):
+            e2, _, _ = g.dev.result()
+            g.err = float(np.sqrt(self.t(e2)))
+            g.err_pending = False
+        return g.err
+
     def record(self, g, kind, tol, s):
-        self.history.append((g.layer, kind, g.itt, 0, float(tol), float(s), float(g.err)))
+        self.history.append((g.layer, kind, g.itt, 0, float(tol), float(s), float(self.level_err(g))))
 
     def history_array(self) -> np.ndarray:
         return np.array(self.history, dtype=HIST_DTYPE)
@@ -162,7 +175,7 @@ class Solver:
             tol = t(abs(t(old_sum - new_sum)) * nr)
             old_sum = new_sum
             self.record(grid, 0, tol, new_sum)
-            self.say(f" itt {grid.itt - old_itt:6d} {float(tol):10.7f} {float(new_sum * nr):10.7f} {grid.err:10.7f}")
+            self.say(f" itt {grid.itt - old_itt:6d} {float(tol):10.7f} {float(new_sum * nr):10.7f} {self.level_err(grid):10.7f}")
 
     def _leg(self, grid, want_sum: bool = False):
         """steps × gs_step between two (print-only) sums: m_gs_CDS.F90:237-248 / :268-278.  Returns the grid_sum
@@ -176,7 +189,8 @@ class Solver:
             self.record(grid, 1, tol, new_sum)
             self.say(f"      {'  ' * grid.layer}{grid.steps:6d} {float(tol):10.7f} {float(new_sum * nr):10.7f}")
             return new_sum
-        return self.gs_steps(grid, grid.steps, want_sum)
+        # nobody reads the residual of an inner leg: its sweeps are enqueued without waiting for them
+        return self.gs_steps(grid, grid.steps, want_sum, fetch=False)
 
     def gs_V(self, pg, cg):
         """m_gs_CDS.F90:220-294.  Returns grid_sum(pg) as it stands when the cycle ends (the sum the caller
@@ -235,7 +249,7 @@ class Solver:
                 itol = t(abs(t(old_sum - new_sum)) * nr)
                 old_sum = new_sum
                 self.record(pg, 2, itol, new_sum)
-                self.say(f" itt {pg.itt - old_itt:6d} {float(itol):10.7f} {float(new_sum * nr):10.7f} {pg.err:10.7f}")
+                self.say(f" itt {pg.itt - old_itt:6d} {float(itol):10.7f} {float(new_sum * nr):10.7f} {self.level_err(pg):10.7f}")
             self.say(f"Completed: {pg.layer}:{cg.layer} in {pg.itt - old_itt} itt. per. lvl")
             if pg.layer == top.layer:
                 cg = pg

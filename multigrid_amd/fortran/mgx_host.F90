@@ -37,6 +37,7 @@ module mgx_host
      real(grid_p) :: a(3) = 1._grid_p / 3._grid_p
      real(grid_p) :: tol = 1.e-4_grid_p
      real(grid_p) :: err = 0._grid_p
+     logical :: err_pending = .false.      ! the last sweeps were only enqueued: err is still in the level's result record
      logical :: enabled = .true.
      type(host_box), allocatable :: box(:)
      type(c_ptr) :: h = c_null_ptr
@@ -154,11 +155,14 @@ contains
 
   ! nsteps x gs_step (m_gs_CDS.F90:296-315) in one enqueue; the sum that follows the last step comes back
   ! with the sweep's own reductions
-  subroutine gs_steps(grid, nsteps, want_sum, new_sum)
+  ! with fetch = .false. (and no sum wanted) nothing waits for the sweeps: the level keeps its result record until
+  ! it is swept again, and level_err reads grid%err from it when somebody asks
+  subroutine gs_steps(grid, nsteps, want_sum, new_sum, fetch)
     type(host_grid), intent(inout) :: grid
     integer, intent(in) :: nsteps
     logical, intent(in) :: want_sum
     real(grid_p), intent(out) :: new_sum
+    logical, intent(in), optional :: fetch
     real(c_double) :: e2, s
     integer(c_int) :: red
     new_sum = 0._grid_p
@@ -170,16 +174,35 @@ contains
     red = MGX_RED_ERR
     if ( want_sum ) red = red + MGX_RED_SUM
     call mgx_check(mgx_level_sweep(grid%h, int(nsteps, c_int), red))
+    if ( present(fetch) ) then
+       if ( .not. fetch .and. .not. want_sum ) then
+          grid%err_pending = .true.
+          return
+       end if
+    end if
     call mgx_check(mgx_level_result(grid%h, e2, s, c_null_ptr))
     grid%err = sqrt(real(e2, grid_p))
+    grid%err_pending = .false.
     if ( want_sum ) then
        if ( s /= s ) stop 'mgx_host: |V| reached 2^20 or is not finite: the iteration diverges'
        new_sum = real(s, grid_p)
     end if
   end subroutine gs_steps
 
+  function level_err(grid) result(e)
+    type(host_grid), intent(inout) :: grid
+    real(grid_p) :: e
+    real(c_double) :: e2, s
+    if ( grid%err_pending ) then
+       call mgx_check(mgx_level_result(grid%h, e2, s, c_null_ptr))
+       grid%err = sqrt(real(e2, grid_p))
+       grid%err_pending = .false.
+    end if
+    e = grid%err
+  end function level_err
+
   subroutine record(grid, kind, tol, s)
-    type(host_grid), intent(in) :: grid
+    type(host_grid), intent(inout) :: grid
     integer, intent(in) :: kind
     real(grid_p), intent(in) :: tol, s
     integer, allocatable :: ti(:)
@@ -204,7 +227,7 @@ contains
     history%itt(history%n) = grid%itt
     history%tol(history%n) = real(tol, c_double)
     history%sum(history%n) = real(s, c_double)
-    history%err(history%n) = real(grid%err, c_double)
+    history%err(history%n) = real(level_err(grid), c_double)
   end subroutine record
 
   ! ---- m_gs_CDS ----------------------------------------------------------------------------------
@@ -271,7 +294,7 @@ contains
        tol = abs(old_sum - new_sum) * nr
        old_sum = new_sum
        call record(grid, 0, tol, new_sum)
-       if ( verbose ) write(*,'(a,i6,3(tr1,f10.7))') ' itt ', grid%itt, tol, new_sum * nr, grid%err
+       if ( verbose ) write(*,'(a,i6,3(tr1,f10.7))') ' itt ', grid%itt, tol, new_sum * nr, level_err(grid)
     end do
   end subroutine grid_solve
 
@@ -289,7 +312,7 @@ contains
        tol = abs(old_sum - new_sum) * nr
        call record(grid, 1, tol, new_sum)
     else
-       call gs_steps(grid, grid%steps, want_sum, new_sum)
+       call gs_steps(grid, grid%steps, want_sum, new_sum, fetch=.false.)   ! nobody reads an inner leg's residual
     end if
     s_end = new_sum
   end subroutine leg
@@ -368,7 +391,7 @@ contains
           itol = abs(old_sum - new_sum) * nr
           old_sum = new_sum
           call record(pg, 2, itol, new_sum)
-          if ( verbose ) write(*,'(a,i6,3(tr1,f10.7))') ' itt ', pg%itt - old_itt, itol, new_sum * nr, pg%err
+          if ( verbose ) write(*,'(a,i6,3(tr1,f10.7))') ' itt ', pg%itt - old_itt, itol, new_sum * nr, level_err(pg)
        end do
        if ( pg%layer == top%layer ) then
           cg => pg

@@ -47,3 +47,29 @@ def test_fortran_host_matches_oracle(name, prec, sub, tmp_path):
     for f in ("tol", "sum", "err"):
         assert np.array_equal(h[f], hist[f]), f
     assert bits_equal(W, V)
+
+
+def test_fortran_host_without_print_only_sums(tmp_path):
+    """`noprint`: no print-only sums, inner legs of a cycle only enqueued; same convergence tests, counts and potential"""
+    name, prec = "solve_80_v", "f64"
+    exe = os.path.join(ROOT, "multigrid_amd", "fortran", f"mg_gpu_{prec}")
+    assert os.path.exists(exe), "build it first: make -C multigrid_amd/fortran"
+    text = str(load(f"{name}_{prec}")["input"]).replace("sor 1.8", "sor 1.6")
+    IO = mgio.MgIO(text=text)
+    top = mgio.iomg_read(IO, dtype=DT[prec])
+    method = mgio.read_method(IO)
+    V, hist, per = orc.solve(oracle_levels(top), method, DT[prec], order=orc.ORDER_RB, sum_mode=orc.SUM_EXACT)
+    keep = hist[hist["kind"] != 1]
+    case, out = str(tmp_path / "case.txt"), str(tmp_path / "out.bin")
+    mgio.write_host_case(top, method, case)
+    r = subprocess.run([exe, case, out, "noprint"], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, universal_newlines=True, timeout=300)
+    assert r.returncode == 0, r.stdout
+    assert "solve seconds" in r.stdout
+    levels = list(top.levels())
+    shape = tuple(int(v) + 2 for v in reversed(levels[0].n))
+    h, per_f, W = mgio.read_host_result(out, len(levels), shape, DT[prec])
+    assert per_f == per
+    assert len(h["itt"]) == len(keep)
+    for f in ("layer", "kind", "itt", "tol", "sum", "err"):
+        assert np.array_equal(h[f], keep[f]), f
+    assert bits_equal(W, V)

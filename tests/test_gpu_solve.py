@@ -69,3 +69,25 @@ def test_divergent_solve_is_reported():
             s.mg_gs_cds(method)
     finally:
         s.close()
+
+
+@pytest.mark.parametrize("name,prec", [("solve_64x48x80_v_half", "f32"), ("solve_80_v", "f64")])
+def test_cycle_without_print_only_sums(name, prec):
+    """print_sums=False leaves out the sums gs_V evaluates only to print them and does not wait for the inner legs of
+    a cycle: the convergence tests (history kinds 0 and 2), the sweep counts and the potential must not change"""
+    IO = mgio.MgIO(text=_input(name, prec))
+    top = mgio.iomg_read(IO, dtype=DT[prec])
+    method = mgio.read_method(IO)
+    V, hist, per = orc.solve(oracle_levels(top), method, DT[prec], order=orc.ORDER_RB, sum_mode=orc.SUM_EXACT)
+    keep = hist[hist["kind"] != 1]
+    s = cycle.Solver(top, print_sums=False)
+    try:
+        s.mg_gs_cds(method)
+        h = s.history_array()
+        assert [l.itt for l in top.levels()] == per
+        assert len(h) == len(keep)
+        for f in ("layer", "kind", "itt", "tol", "sum", "err"):
+            assert np.array_equal(h[f], keep[f]), f
+        assert bits_equal(top.dev.download(), V)
+    finally:
+        s.close()
