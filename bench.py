@@ -133,6 +133,7 @@ def main():
     ap.add_argument("--size", dest="n", type=int, default=512, help="cells per dimension of one GPU's slab")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-vcycle", action="store_true")
+    ap.add_argument("--no-fortran-host", action="store_true", help="skip the v-cycle solve through the Fortran host")
     ap.add_argument("--vcycle-tol", default="1.e-8")
     ap.add_argument("--sor", default="1.7")
     ap.add_argument("--kernel", type=int, default=0, help="0 auto, 1 two-pass, 2 fused")
@@ -260,7 +261,7 @@ def main():
                          "final_err": float(h["err"][-1]) if len(h) else None,
                          "lattice_updates": int(sum(int(g.itt) * int(np.prod(g.n)) for g in top.levels()))}
     exe = os.path.join(ROOT, "multigrid_amd", "fortran", "mg_gpu_f64")
-    if world == 1 and not args.no_vcycle and os.path.exists(exe):
+    if world == 1 and not args.no_vcycle and not args.no_fortran_host and os.path.exists(exe):
         # the same solve driven by the Fortran host (the reference's cycle control over the C ABI, ISO_C_BINDING), as
         # a child process with a context of its own
         with tempfile.TemporaryDirectory() as td:

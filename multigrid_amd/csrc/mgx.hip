@@ -394,9 +394,11 @@ template <typename T>
 static int sync_shell(mgx_level *lv) {
   if (lv->shell_synced) return MGX_OK;
   const MgxGeom &g = lv->g;
-  dim3 grid(std::max(1, std::min(8, (g.n1 + 2 + 255) / 256)), g.n2 + 2, g.n3 + 4);
-  hipLaunchKernelGGL((k_copy_shell<T>), grid, dim3(256), 0, C(lv)->stream, (const T *)lv->buf[lv->cur],
-                     (T *)lv->buf[1 - lv->cur], g);
+  const long long nrows = 4LL * (g.n2 + 2) + 2LL * g.n3;
+  const long long blocks = nrows + ((long long)g.n2 * g.n3 + 255) / 256;
+  if (blocks > 0x7fffffffLL) return fail(MGX_ELIMIT, "mgx_level_sweep: level too large for the shell copy");
+  hipLaunchKernelGGL((k_copy_shell<T>), dim3((unsigned)blocks), dim3(256), 0, C(lv)->stream, (const T *)lv->buf[lv->cur],
+                     (T *)lv->buf[1 - lv->cur], g, (int)nrows);
   HIP_TRY(hipGetLastError());
   lv->shell_synced = true;
   return MGX_OK;

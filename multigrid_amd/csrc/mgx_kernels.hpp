@@ -284,18 +284,34 @@ __global__ __launch_bounds__(256) void k_face(T *__restrict__ V, const MgxGeom g
   V[g.idx(c[0], c[1], c[2])] = (src < 0) ? (T)0 : V[g.idx(s[0], s[1], s[2])];
 }
 
-// copy the ghost shell (x = 0, n1+1; y = 0, n2+1; z planes outside 1..n3) from one buffer to the other
+// copy the ghost shell (x = 0, n1+1; y = 0, n2+1; z planes outside 1..n3) from one buffer to the other.
+// Blocks 0 .. nrows-1 copy one whole row each: the rows of the four planes outside 1..n3, then rows y = 0 and
+// y = n2+1 of the planes 1..n3.  The blocks after them take one inner row (y in 1..n2, z in 1..n3) per thread and
+// copy its two ends.
 template <typename T>
-__global__ __launch_bounds__(256) void k_copy_shell(const T *__restrict__ src, T *__restrict__ dst, const MgxGeom g) {
-  const int z = (int)blockIdx.z - 1;                   // -1 .. n3+2
-  const int y = blockIdx.y;                            // 0 .. n2+1
-  const bool whole_row = (z < 1 || z > g.n3 || y == 0 || y == g.n2 + 1);
-  for (int x = blockIdx.x * blockDim.x + threadIdx.x; x <= g.n1 + 1; x += gridDim.x * blockDim.x) {
-    if (whole_row || x == 0 || x == g.n1 + 1) {
-      const long long c = g.idx(x, y, z);
-      dst[c] = src[c];
+__global__ __launch_bounds__(256) void k_copy_shell(const T *__restrict__ src, T *__restrict__ dst, const MgxGeom g, const int nrows) {
+  const int b = blockIdx.x;
+  if (b < nrows) {
+    int y, z;
+    const int outer = 4 * (g.n2 + 2);
+    if (b < outer) {
+      const int pl = b / (g.n2 + 2);                   // planes -1, 0, n3+1, n3+2
+      z = pl < 2 ? pl - 1 : g.n3 + pl - 1;
+      y = b % (g.n2 + 2);
+    } else {
+      z = 1 + (b - outer) / 2;
+      y = ((b - outer) & 1) ? g.n2 + 1 : 0;
     }
+    const long long c = g.idx(0, y, z);
+    for (int x = threadIdx.x; x <= g.n1 + 1; x += 256) dst[c + x] = src[c + x];
+    return;
   }
+  const long long t = (long long)(b - nrows) * 256 + threadIdx.x;
+  if (t >= (long long)g.n2 * g.n3) return;
+  const int y = 1 + (int)(t % g.n2), z = 1 + (int)(t / g.n2);
+  const long long c = g.idx(0, y, z);
+  dst[c] = src[c];
+  dst[c + g.n1 + 1] = src[c + g.n1 + 1];
 }
 
 template <typename T> struct MgxPair;
