@@ -136,6 +136,7 @@ extern "C" int mgx_ctx_create(int device, void *stream, mgx_ctx **out) {
   if (const char *e = getenv("MGX_FUSED_TY")) mgx_fused_ty = atoi(e);   // tile-height override for benchmarking
   if (const char *e = getenv("MGX_FUSED_NW")) mgx_fused_nw = atoi(e);
   if (const char *e = getenv("MGX_FUSED_ZC")) mgx_fused_zc = atoi(e);
+  if (const char *e = getenv("MGX_FUSED_TAIL")) mgx_fused_tail = atoi(e);
   if (stream) {
     c->stream = (hipStream_t)stream;
   } else {

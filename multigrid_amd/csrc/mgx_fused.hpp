@@ -548,19 +548,19 @@ __device__ __forceinline__ void mgx_fused_body(const T *__restrict__ src, T *__r
   if (reduce) mgx_block_commit<NW + 1>((double)(err * err), slo, shi, ovf, reduce, res);
 }
 
-// One launch per sweep.  `tiles` lists the tiles (x fastest, then y, then z chunk) in three segments, each padded
-// with -1 to a multiple of 8 blocks: tiles that some box with rho != 1 reaches (they take longest, so they are
-// dispatched first), tiles that only boxes with rho = 1 reach, tiles no box reaches.  The host builds the list
-// from the box table.
+// One launch per sweep.  `tiles` lists the pieces of work in dispatch order, three ints each: tile column (x
+// fastest, then y; -1 = padding), first and last plane of the z chunk.  Three segments, each a multiple of 8
+// blocks: pieces that some box with rho != 1 reaches (they take longest, so they are dispatched first), pieces
+// that only boxes with rho = 1 reach, pieces no box reaches.  The host builds the list from the box table and
+// orders it so that the blocks of one XCD (block index mod 8) are neighbouring tiles.
 template <typename T, int TY, int BOXES, int NW>
 __device__ __forceinline__ void mgx_fused_tile(const T *__restrict__ src, T *__restrict__ dst, const MgxGeom &g,
                                                const MgxSweepParams<T> &p, const MgxBox *__restrict__ bx, const int nb,
-                                               const int ZC, const int ntx, const int nty, const int tile, const int reduce,
+                                               const int ntx, const int tile, const int zc0, const int zc1, const int reduce,
                                                u64 *__restrict__ res, T *__restrict__ lds, MgxBoxLds<T> *__restrict__ bl) {
   constexpr int TXP = 64;
-  const int tx = tile % ntx, ty = (tile / ntx) % nty, tz = tile / (ntx * nty);
+  const int tx = tile % ntx, ty = tile / ntx;
   const int tx0 = 1 + tx * 2 * TXP, ty0 = 1 + ty * TY;
-  const int zc0 = 1 + tz * ZC, zc1 = min(zc0 + ZC - 1, g.n3);
   // parity of y + z (global) of the wave's first item on the first plane of the march, zc0 - 1
   const int wave = threadIdx.x >> 6;
   const bool halo = wave == NW;
@@ -577,7 +577,7 @@ __device__ __forceinline__ void mgx_fused_tile(const T *__restrict__ src, T *__r
 template <typename T, int TY, int NW>
 __global__ __launch_bounds__((NW + 1) * 64) void k_fused_sweep(const T *__restrict__ src, T *__restrict__ dst, const MgxGeom g,
                                                      const MgxSweepParams<T> p, const MgxBox *__restrict__ bx,
-                                                     const int nb, const int ZC, const int ntx, const int nty,
+                                                     const int nb, const int ntx,
                                                      const int *__restrict__ tiles, const int n_box, const int n_const,
                                                      const int reduce, u64 *__restrict__ res) {
   constexpr int TXP = 64;
@@ -585,18 +585,13 @@ __global__ __launch_bounds__((NW + 1) * 64) void k_fused_sweep(const T *__restri
   T *lds = reinterpret_cast<T *>(mgx_lds_raw);          // [slot 0..2][black, red][pairs of a staged plane]
   MgxBoxLds<T> *bl = reinterpret_cast<MgxBoxLds<T> *>(lds + 3 * 2 * (TXP + 2) * (TY + 6));
 
-  // segment of this block (all three sizes are multiples of 8); inside a segment the blocks that share an XCD
-  // (same blockIdx % 8) get consecutive list entries, i.e. neighbouring tiles
   const int b = blockIdx.x;
   const int cls = b < n_box ? 2 : b < n_box + n_const ? 1 : 0;
-  const int base = cls == 2 ? 0 : cls == 1 ? n_box : n_box + n_const;
-  const int cnt = cls == 2 ? n_box : cls == 1 ? n_const : (int)gridDim.x - base;
-  const int bs = b - base;
-  const int tile = tiles[base + (bs & 7) * (cnt >> 3) + (bs >> 3)];
+  const int tile = tiles[3 * b], zc0 = tiles[3 * b + 1], zc1 = tiles[3 * b + 2];
   if (tile < 0) return;                                 // padding (the whole block leaves before any barrier)
-  if (cls == 2) mgx_fused_tile<T, TY, 2, NW>(src, dst, g, p, bx, nb, ZC, ntx, nty, tile, reduce, res, lds, bl);
-  else if (cls == 1) mgx_fused_tile<T, TY, 1, NW>(src, dst, g, p, bx, nb, ZC, ntx, nty, tile, reduce, res, lds, bl);
-  else mgx_fused_tile<T, TY, 0, NW>(src, dst, g, p, bx, nb, ZC, ntx, nty, tile, reduce, res, lds, bl);
+  if (cls == 2) mgx_fused_tile<T, TY, 2, NW>(src, dst, g, p, bx, nb, ntx, tile, zc0, zc1, reduce, res, lds, bl);
+  else if (cls == 1) mgx_fused_tile<T, TY, 1, NW>(src, dst, g, p, bx, nb, ntx, tile, zc0, zc1, reduce, res, lds, bl);
+  else mgx_fused_tile<T, TY, 0, NW>(src, dst, g, p, bx, nb, ntx, tile, zc0, zc1, reduce, res, lds, bl);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -604,7 +599,7 @@ __global__ __launch_bounds__((NW + 1) * 64) void k_fused_sweep(const T *__restri
 
 struct MgxTileList {             // segment sizes, each padded to a multiple of 8, and where the list starts
   int n_fast = 0, n_const = 0, n_box = 0;
-  int offset = 0;                // into MgxFusedPlan::d_tiles: n_box entries, then n_const, then n_fast; -1 = padding
+  int offset = 0;                // entry (3 ints each) in MgxFusedPlan::d_tiles: n_box entries, n_const, n_fast; -1 = padding
 };
 
 struct MgxFusedPlan {            // per level: tile decomposition and the tile lists (device)
@@ -619,6 +614,7 @@ struct MgxFusedPlan {            // per level: tile decomposition and the tile l
 static int mgx_fused_ty = 0;     // tile height override (0 = automatic), settable for benchmarking
 static int mgx_fused_nw = 0;     // row waves per block override (4 or 8)
 static int mgx_fused_zc = 0;     // z chunk override (0 = automatic)
+static int mgx_fused_tail = -1;  // percent of the box-free chunks cut into halves, and half as many again into quarters (-1 = automatic)
 
 // (re)build the plan: which tiles can any box reach?  A tile asks about cells of its footprint grown by
 // one and about their neighbours, i.e. positions grown by two, on planes zc0-2 .. zc1+2.
@@ -648,39 +644,71 @@ static int mgx_fused_make_plan(MgxFusedPlan &pl, const MgxGeom &g, const std::ve
   pl.nzc = (g.n3 + ZC - 1) / ZC;
   const long long ntile = per_chunk * pl.nzc;
   if (ntile > 0x7fffffffLL) return -1;
+  // Blocks are dispatched in index order, block b to XCD b mod 8, one block per compute unit.  Chunks that differ
+  // in cost must therefore come in groups of 8 equal ones (or an XCD that got the long ones holds up the
+  // dispatch of all), and the last blocks to start decide when the sweep ends: of the box-free chunks of a large
+  // level, 12 % are cut into halves and 6 % into quarters, dispatched last in that order, so that the compute
+  // units run dry within a quarter chunk of each other (measured at 512^3: 2 % to 6 % per sweep; larger
+  // fractions lose it again to the four planes every piece reads ahead of its first).
+  struct Piece { int col, z0, z1; };
+  int tail = mgx_fused_tail >= 0 ? mgx_fused_tail : (ZC >= 32 && ntile >= 512 ? 12 : 0);
+  if (tail > 60) tail = 60;
   std::vector<int> all;
-  for (int sel = 0; sel < 3; ++sel) {
-    std::vector<int> fast, consto, boxed;   // no box in reach / only rho = 1 boxes / some box with rho != 1
+  auto classify = [&](int tx, int ty, int a, int b) {
+    const int x0 = 1 + tx * 2 * TXP - 2, x1 = 1 + (tx + 1) * 2 * TXP + 1;
+    const int y0 = 1 + ty * pl.ty - 2, y1 = 1 + (ty + 1) * pl.ty + 1;
+    const int z0 = a - 2 + g.z0, z1 = b + 2 + g.z0;
+    int c = 0;
+    for (const MgxBox &bb : boxes)
+      if (bb.lo[0] <= x1 && x0 <= bb.hi[0] && bb.lo[1] <= y1 && y0 <= bb.hi[1] && bb.lo[2] <= z1 && z0 <= bb.hi[2])
+        c = std::max(c, bb.rho_is_one ? 1 : 2);
+    return c;
+  };
+  // the groups of the whole level: [0] rho boxes, [1] constant boxes only, [2] box-free whole, [3] halves, [4] quarters
+  std::vector<Piece> grp[5];
+  {
+    std::vector<Piece> fast;
     for (int tz = 0; tz < pl.nzc; ++tz) {
-      const bool edge = 1 + tz * ZC <= 2 || std::min((tz + 1) * ZC, g.n3) >= g.n3 - 1;   // holds plane 1, 2, n3-1 or n3
-      if ((sel == 1 && !edge) || (sel == 2 && edge)) continue;
+      const int zc0 = 1 + tz * ZC, zc1 = std::min(zc0 + ZC - 1, g.n3);
       for (int ty = 0; ty < pl.nty; ++ty)
         for (int tx = 0; tx < pl.ntx; ++tx) {
-          const int x0 = 1 + tx * 2 * TXP - 2, x1 = 1 + (tx + 1) * 2 * TXP + 1;
-          const int y0 = 1 + ty * pl.ty - 2, y1 = 1 + (ty + 1) * pl.ty + 1;
-          const int zc0 = 1 + tz * ZC, zc1 = std::min(zc0 + ZC - 1, g.n3);
-          const int z0 = zc0 - 2 + g.z0, z1 = zc1 + 2 + g.z0;
-          bool hit = false, hit_rho = false;
-          for (const MgxBox &b : boxes) {
-            const bool h = b.lo[0] <= x1 && x0 <= b.hi[0] && b.lo[1] <= y1 && y0 <= b.hi[1] && b.lo[2] <= z1 && z0 <= b.hi[2];
-            hit |= h;
-            hit_rho |= h && !b.rho_is_one;
-          }
-          (hit_rho ? boxed : hit ? consto : fast).push_back((tz * pl.nty + ty) * pl.ntx + tx);
+          const int c = classify(tx, ty, zc0, zc1);
+          (c == 2 ? grp[0] : c == 1 ? grp[1] : fast).push_back({ty * pl.ntx + tx, zc0, zc1});
         }
     }
-    for (std::vector<int> *v : {&boxed, &consto, &fast})
-      while (v->size() % 8) v->push_back(-1);
-    MgxTileList &tl = pl.list[sel];
-    tl.n_fast = (int)fast.size();
-    tl.n_const = (int)consto.size();
-    tl.n_box = (int)boxed.size();
-    tl.offset = (int)all.size();
-    all.insert(all.end(), boxed.begin(), boxed.end());
-    all.insert(all.end(), consto.begin(), consto.end());
-    all.insert(all.end(), fast.begin(), fast.end());
+    const size_t nq = fast.size() * (size_t)tail / 200, nh = fast.size() * (size_t)tail / 100;
+    const size_t nwhole = fast.size() - std::min(fast.size(), nq + nh);
+    for (size_t i = 0; i < fast.size(); ++i) {
+      const Piece &f = fast[i];
+      const int parts = i < nwhole ? 1 : i < nwhole + nh ? 2 : 4;
+      const int len = f.z1 - f.z0 + 1, plen = std::max(4, (len + parts - 1) / parts);
+      if (parts == 1 || len <= plen) { grp[2].push_back(f); continue; }
+      for (int a = f.z0; a <= f.z1; a += plen) grp[parts == 2 ? 3 : 4].push_back({f.col, a, std::min(a + plen - 1, f.z1)});
+    }
   }
-  if (all.empty()) all.push_back(-1);
+  for (int sel = 0; sel < 3; ++sel) {
+    MgxTileList &tl = pl.list[sel];
+    tl.offset = (int)all.size() / 3;
+    int count[3] = {0, 0, 0};
+    for (int gi = 0; gi < 5; ++gi) {
+      std::vector<Piece> v;
+      for (const Piece &q : grp[gi]) {
+        const bool edge = q.z0 <= 2 || q.z1 >= g.n3 - 1;     // holds plane 1, 2, n3-1 or n3
+        if (sel == 0 || (sel == 1) == edge) v.push_back(q);
+      }
+      while (v.size() % 8) v.push_back({-1, 0, 0});
+      const size_t per = v.size() / 8;
+      for (size_t i = 0; i < v.size(); ++i) {                // block i of the group runs on XCD i mod 8: give every
+        const Piece &q = v[(i & 7) * per + (i >> 3)];        // XCD a contiguous run of the group (neighbouring tiles)
+        all.push_back(q.col); all.push_back(q.z0); all.push_back(q.z1);
+      }
+      count[gi == 0 ? 0 : gi == 1 ? 1 : 2] += (int)v.size();
+    }
+    tl.n_box = count[0];
+    tl.n_const = count[1];
+    tl.n_fast = count[2];
+  }
+  if (all.empty()) all.insert(all.end(), {-1, 0, 0});
   if (hipMalloc((void **)&pl.d_tiles, sizeof(int) * all.size()) != hipSuccess) return -1;
   if (hipMemcpyAsync(pl.d_tiles, all.data(), sizeof(int) * all.size(), hipMemcpyHostToDevice, st) != hipSuccess) return -1;
   if (hipStreamSynchronize(st) != hipSuccess) return -1;     // `all` goes out of scope
@@ -702,7 +730,7 @@ static int mgx_fused_launch_cfg(const MgxFusedPlan &pl, int part, const T *src, 
   const int total = tl.n_box + tl.n_const + tl.n_fast;
   if (total > 0)
     hipLaunchKernelGGL((k_fused_sweep<T, TY, NW>), dim3((unsigned)total), dim3((NW + 1) * 64), lds, st, src, dst, g, p, bx, nb,
-                       pl.ZC, pl.ntx, pl.nty, pl.d_tiles + tl.offset, tl.n_box, tl.n_const, reduce, res);
+                       pl.ntx, pl.d_tiles + 3 * tl.offset, tl.n_box, tl.n_const, reduce, res);
   return 0;
 }
 
