@@ -1,0 +1,57 @@
+"""`python -m multigrid_amd [--double] [input]` — the reference's `mg` program (src/mg.F90:58-135) over the HIP library:
+read the input file (default mg.input), take the `method` line, write the `init-save` files from the set-up state,
+solve on the GPU, write the `save` files (default mg.vmg).  Files are the binary .VMG container
+(src/m_mg_save.F90:231-267); the file type follows the reference's rule on the extension (:45-62: everything that
+is not `cube` is binary; `vmgasc` is shadowed by `vmg`), and the cube writer is not part of this package.
+`--double` runs in real(8) (the reference as shipped is real(4), t_mg.f90:8)."""
+from __future__ import annotations
+
+import sys
+
+import numpy as np
+
+from . import cycle, mgio
+from . import grid as G
+
+
+def mg_save(top: G.MgGrid, filename: str, V: np.ndarray) -> str:
+    i = filename.find(".")
+    if i >= 0 and filename[i + 1:i + 5].lower() == "cube":
+        raise G.MgStop("cube files are not written by this package: use a .vmg name")
+    path = mgio.vmg_name(filename)
+    mgio.write_vmg(path, top, V)
+    return path
+
+
+def main(argv=None) -> int:
+    argv = sys.argv[1:] if argv is None else argv
+    precision = np.float64 if "--double" in argv else np.float32
+    argv = [a for a in argv if not a.startswith("--")]
+    filein = argv[-1] if argv else "mg.input"        # the last argument, as in mg.F90:60-66
+    IO = mgio.MgIO(path=filein)
+    top = mgio.iomg_read(IO, dtype=precision)
+    method = mgio.read_method(IO)
+    solver = cycle.Solver(top, verbose=True)
+    try:
+        names = mgio.save_names(IO, "init-save")
+        if names:
+            solver.bring_back(top)
+            solver.setup(top, True)
+            V = top.dev.download()
+            for name in names:
+                print("Saved", mg_save(top, name, V))
+            solver.hold_back(top)
+        solver.mg_gs_cds(method)
+        V = top.dev.download()
+        for name in mgio.save_names(IO, "save") or ["mg.vmg"]:
+            print("Saved", mg_save(top, name, V))
+    except G.MgStop as e:
+        print(e, file=sys.stderr)
+        return 1
+    finally:
+        solver.close()
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())

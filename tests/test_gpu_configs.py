@@ -45,3 +45,19 @@ def test_config4_elongated(prec):
     top, per = _solve_and_compare(config4_input(), DT[prec])
     assert [tuple(int(v) for v in g.n) for g in top.levels()] == [(40, 40, 640), (20, 20, 320), (20, 20, 160), (20, 20, 80)]
     assert [g.tol for g in top.levels()] == [1e-3, 1e-3, 1e-3, 1e-4]
+
+
+def test_mg_program_runs_test6_input(tmp_path, monkeypatch):
+    """`python -m multigrid_amd <input>`: the reference's mg program on its own test input, fp32 as shipped; the saved
+    .VMG holds the oracle's potential (planes 1..n3 with their x/y ghosts)"""
+    from multigrid_amd import __main__ as mg
+    text = str(load("test6_f32")["input"])
+    (tmp_path / "t6.input").write_text(text)
+    monkeypatch.chdir(tmp_path)
+    assert mg.main([str(tmp_path / "t6.input")]) == 0
+    IO = mgio.MgIO(text=text)
+    top = mgio.iomg_read(IO, dtype=np.float32)
+    V, _, _ = orc.solve(oracle_levels(top), mgio.read_method(IO), np.float32, order=orc.ORDER_RB, sum_mode=orc.SUM_EXACT)
+    n, offset, cell, planes = mgio.read_vmg(str(tmp_path / "out.VMG"), np.float32)
+    assert [int(v) for v in n] == [240, 150, 240]
+    assert bits_equal(planes, V[1:-1])
