@@ -6,7 +6,9 @@ sum|V| reductions that the host convergence loop reads, m_gs_CDS.F90:200-210) of
 of the 512^3 mixed-boundary configuration, fp64, field resident in HBM.  `value` = lattice updates
 per second of the whole job (all ranks).  With --gpus N > 1 the level is z-slab decomposed, every
 rank owning a 512 x 512 x 512 slab of a 512 x 512 x (512 N) level (weak scaling): two halo planes
-per neighbour are exchanged per sweep over RCCL and the reductions are all-reduced.
+per neighbour are exchanged per sweep over RCCL and the reductions are all-reduced; afterwards rank 0
+repeats the sweeps on the undivided level and reports whether the reductions agree bit for bit
+(`check.undivided.identical`).
 
 The JSON line also carries
   roofline      achieved HBM GB/s of the sweep kernel (16 B per lattice update: one read + one write
@@ -141,6 +143,8 @@ def main():
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for --gpus > 1 (nccl = RCCL)")
     ap.add_argument("--dist-vcycle", action="store_true",
                     help="with --gpus > 1: also time the complete v-cycle solve with every level decomposed into z slabs")
+    ap.add_argument("--no-verify", action="store_true",
+                    help="with --gpus > 1: skip the comparison of the reductions with the undivided level on rank 0")
     ap.add_argument("--no-overlap", action="store_true", help="exchange the halo planes after the whole sweep")
     args = ap.parse_args()
 
@@ -230,6 +234,21 @@ def main():
         "hbm_peak_pct": 100.0 * achieved / HBM_PEAK_GBS,
         "check": {"err_sq_max": e2, "abs_sum": s},
     }
+    if world > 1 and not args.no_verify:
+        # rank 0 repeats the same sweeps on the undivided level (it fits one GPU) and compares the reductions of the
+        # last sweep bit for bit: red-black results and the exact sum do not depend on the decomposition
+        if rank == 0:
+            from multigrid_amd import grid as G
+            whole = ctx.level(top.layer, [int(v) for v in top.n], top.dtype)
+            whole.set_params(top.sor, [float(v) for v in top.a], top.bc6())
+            whole.set_boxes(*G.box_table(top))
+            whole.bring_back()
+            whole.setup(True)
+            whole.sweep(args.warmup + args.steps, lib.RED_ERR | lib.RED_SUM)
+            we2, ws, _ = whole.result()
+            whole.close()
+            out["check"]["undivided"] = {"err_sq_max": we2, "abs_sum": ws, "identical": bool(we2 == e2 and ws == s)}
+        barrier()
     tr = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tr):
         try:
