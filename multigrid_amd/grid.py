@@ -126,6 +126,12 @@ def init_grid(grid: MgGrid, n: Sequence[int], cell, boxes: int, tol: Optional[fl
     grid.box = [MgBox() for _ in range(grid.N_box)]
 
 
+def g2g(n1: int, i1: int, n2: int) -> int:
+    """index i1 of a grid with n1 cells seen from a grid with n2 cells along the same direction
+    (t_mg_interp.f90:995-999: integer division, clamped to 1..n2); the transfer kernels' index tables hold this map"""
+    return max(1, min(int(i1) * int(n2) // int(n1), int(n2)))
+
+
 def _new_grid_size(grid: MgGrid):
     """t_mg.f90:183-201"""
     n = [int(v) // 2 for v in grid.n]

@@ -104,3 +104,39 @@ def test_setup_all_bc_combinations(ctx, prec):
     orc.setup(L, V, True)
     assert bits_equal(lv.download(), V)
     lv.close()
+
+
+@pytest.mark.parametrize("prec", ["f32", "f64"])
+@pytest.mark.parametrize("i", [8, 9, 10, 11, 12, 13, 14, 15, 128])
+def test_reference_test1_constant_field(ctx, i, prec):
+    """the reference's test/test1.f90 on the GPU: parent i^3 holding 1, child ((i + mod(i,2))/2 - 1)^3 (not a halving,
+    generic index maps); restriction and prolongation against the oracle bit for bit, and the known answer: maximum 1"""
+    from multigrid_amd import lib
+    dt = DT[prec]
+    nc = (i + i % 2) // 2 - 1
+    for method in (1, 2):
+        eps = 0.0 if method == 1 else 4 * float(np.finfo(dt).eps)
+        P = orc.Level(n=(i, i, i), res_method=method)
+        Cl = orc.Level(n=(nc, nc, nc), pro_method=method)
+        dp, dc = dev_level(ctx, P, dt, 1), dev_level(ctx, Cl, dt, 2)
+        try:
+            Vp = np.ones(P.shape(), dtype=dt)
+            Vc = np.zeros(Cl.shape(), dtype=dt)
+            orc.restrict(P, Vp, Cl, Vc)
+            dp.upload(Vp)
+            dc.bring_back()
+            lib.restrict(dp, dc, method)
+            W = dc.download()
+            assert bits_equal(W, Vc)
+            assert abs(float(W.max()) - 1.0) <= eps
+            Vc[...] = 1
+            dc.upload(Vc)
+            orc.prolong(Cl, Vc, P, Vp)
+            dp.bring_back()
+            lib.prolong(dc, dp, method)
+            W = dp.download()
+            assert bits_equal(W, Vp)
+            assert abs(float(W[1:-1, 1:-1, 1:-1].max()) - 1.0) <= eps
+        finally:
+            dp.close()
+            dc.close()

@@ -97,3 +97,23 @@ def test_vmg_roundtrip(tmp_path):
     mgio.write_vmg(p, top, V)
     n, off, cell, W = mgio.read_vmg(p, np.float32)
     assert n.tolist() == [5, 4, 3] and np.array_equal(W, V[1:-1]) and np.array_equal(cell, top.cell)
+
+
+def test_reference_test7_index_maps():
+    """the reference's test/test7.f90 on its own 200^3 hierarchy (max_layer 4): walking a parent direction, g2g reaches
+    every child index and none beyond; walking a child direction, it reaches as many distinct parent indices as the
+    child has cells, none beyond the parent"""
+    from multigrid_amd import grid as G
+    top = G.MgGrid(np.dtype(np.float32))
+    cell = np.diag([31.75, 20.0, 31.75])
+    G.init_grid(top, [200, 200, 200], cell, 4, tol=1e-4)
+    G.init_grid_children_half(top, max_layer=4)
+    levels = list(top.levels())
+    assert [int(g.n[0]) for g in levels] == [200, 100, 50, 25]
+    for g, c in zip(levels[:-1], levels[1:]):
+        for i in range(3):
+            n, nc = int(g.n[i]), int(c.n[i])
+            down = [G.g2g(n, p, nc) for p in range(1, n + 1)]
+            assert max(down) <= nc and len(set(down)) == nc
+            up = [G.g2g(nc, p, n) for p in range(1, nc + 1)]
+            assert max(up) <= n and len(set(up)) == nc

@@ -74,3 +74,25 @@ def test_exact_sum_is_order_independent_and_close_to_seq():
     Vp[1:-1, 1:-1, 1:-1] = Vp[1:-1, 1:-1, 1:-1][::-1, ::-1, ::-1]
     assert orc.abs_sum_exact(L, Vp)[1] == big
     assert abs(s - orc.abs_sum_seq(L, V)) <= 1e-12 * s
+
+
+@pytest.mark.parametrize("i", [8, 9, 10, 11, 12, 13, 14, 15, 128])
+def test_reference_test1_constant_field(i):
+    """the reference's own known answer (test/test1.f90:27-75, printed with three digits): a parent of i^3 cells
+    holding 1 everywhere, a child of ((i + mod(i,2))/2 - 1)^3 cells (not a halving); the maximum after restriction
+    and after prolongation is 1 — exactly with the /64 weights, to rounding with the /56 weights — and no cell
+    an operator wrote exceeds it"""
+    nc = (i + i % 2) // 2 - 1
+    for method in (1, 2):
+        eps = 0.0 if method == 1 else 4 * np.finfo(np.float64).eps
+        P = orc.Level(n=(i, i, i), res_method=method)
+        Cl = orc.Level(n=(nc, nc, nc), pro_method=method)
+        Vp = np.ones(P.shape(), dtype=np.float64)
+        Vc = np.zeros(Cl.shape(), dtype=np.float64)
+        orc.restrict(P, Vp, Cl, Vc)
+        assert abs(Vc.max() - 1.0) <= eps
+        if method == 2:                       # the half-weight loop writes every child cell
+            assert np.abs(Vc[1:-1, 1:-1, 1:-1] - 1.0).max() <= eps
+        Vc[...] = 1.0
+        orc.prolong(Cl, Vc, P, Vp)            # child ghosts hold 1 as well: every stencil sees only ones
+        assert np.abs(Vp[1:-1, 1:-1, 1:-1] - 1.0).max() <= eps
