@@ -613,6 +613,7 @@ struct MgxFusedPlan {            // per level: tile decomposition and the tile l
 
 static int mgx_fused_ty = 0;     // tile height override (0 = automatic), settable for benchmarking
 static int mgx_fused_nw = 0;     // row waves per block override (4 or 8)
+#define MGX_EDGE_PLANES 8        /* planes at either end of a slab swept ahead of the halo exchange */
 static int mgx_fused_zc = 0;     // z chunk override (0 = automatic)
 static int mgx_fused_tail = -1;  // percent of the box-free chunks cut into halves, and half as many again into quarters (-1 = automatic)
 
@@ -668,12 +669,22 @@ static int mgx_fused_make_plan(MgxFusedPlan &pl, const MgxGeom &g, const std::ve
   std::vector<Piece> grp[5];
   {
     std::vector<Piece> fast;
-    for (int tz = 0; tz < pl.nzc; ++tz) {
-      const int zc0 = 1 + tz * ZC, zc1 = std::min(zc0 + ZC - 1, g.n3);
+    // z ranges: chunks of ZC planes; a slab of a decomposed level first gets its lowest and highest MGX_EDGE_PLANES
+    // planes as ranges of their own: they hold the planes the neighbours wait for, and the part of the sweep that
+    // must finish before the exchange starts (MGX_PART_EDGE) is then a single short round of blocks
+    std::vector<std::pair<int, int>> zr;
+    const bool carve = g.n3 != g.n3g && g.n3 >= 4 * MGX_EDGE_PLANES && ZC > MGX_EDGE_PLANES;
+    const int zfirst = carve ? 1 + MGX_EDGE_PLANES : 1, zlast = carve ? g.n3 - MGX_EDGE_PLANES : g.n3;
+    if (carve) zr.push_back({1, MGX_EDGE_PLANES});
+    for (int a = zfirst; a <= zlast; a += ZC) zr.push_back({a, std::min(a + ZC - 1, zlast)});
+    if (carve) zr.push_back({zlast + 1, g.n3});
+    for (size_t iz = 0; iz < zr.size(); ++iz) {
+      const int zc0 = zr[iz].first, zc1 = zr[iz].second;
+      const bool carved = carve && (iz == 0 || iz + 1 == zr.size());
       for (int ty = 0; ty < pl.nty; ++ty)
         for (int tx = 0; tx < pl.ntx; ++tx) {
           const int c = classify(tx, ty, zc0, zc1);
-          (c == 2 ? grp[0] : c == 1 ? grp[1] : fast).push_back({ty * pl.ntx + tx, zc0, zc1});
+          (c == 2 ? grp[0] : c == 1 ? grp[1] : carved ? grp[4] : fast).push_back({ty * pl.ntx + tx, zc0, zc1});
         }
     }
     const size_t nq = fast.size() * (size_t)tail / 200, nh = fast.size() * (size_t)tail / 100;

@@ -56,7 +56,11 @@ def device_plane_tensor(lv: "lib.DeviceLevel", z: int, count: int):
                            "bind to the HIP runtime PyTorch ships, or torch cannot see the planes")
     import torch
     ptr, nbytes = lv.plane_ptr(z, count)
-    return torch.as_tensor(_DevicePlanes(ptr, nbytes), device=torch.device("cuda", lv.ctx.device))
+    cache = lv.__dict__.setdefault("_plane_tensors", {})      # a level has two buffers: a handful of distinct runs
+    t = cache.get((ptr, nbytes))
+    if t is None:
+        t = cache[(ptr, nbytes)] = torch.as_tensor(_DevicePlanes(ptr, nbytes), device=torch.device("cuda", lv.ctx.device))
+    return t
 
 
 class SlabLevel:
