@@ -279,6 +279,17 @@ def main():
                          "levels": [[int(v) for v in g.n] for g in top.levels()],
                          "final_err": float(h["err"][-1]) if len(h) else None,
                          "lattice_updates": int(sum(int(g.itt) * int(np.prod(g.n)) for g in top.levels()))}
+        if status == "converged":
+            # the timed steps above start from the set-up state (most of the field still zero); the same step on the
+            # converged potential, for comparison: sweep time depends on the values (bit activity), not on the path
+            for _ in range(3):
+                step()
+            torch.cuda.synchronize()
+            ts0 = time.perf_counter()
+            for _ in range(20):
+                step()
+            torch.cuda.synchronize()
+            out["vcycle"]["ms_per_step_on_solution"] = (time.perf_counter() - ts0) / 20 * 1e3
     exe = os.path.join(ROOT, "multigrid_amd", "fortran", "mg_gpu_f64")
     if world == 1 and not args.no_vcycle and not args.no_fortran_host and os.path.exists(exe):
         # the same solve driven by the Fortran host (the reference's cycle control over the C ABI, ISO_C_BINDING), as
