@@ -82,7 +82,8 @@ def test_sweeps_and_transfers_match_oracle(ctx, hierarchy):
 
 def test_two_kernels_and_two_slabs_agree(ctx, hierarchy):
     """eight sweeps from the set-up state: fused kernel, two-pass kernel and a pair of z slabs (halo planes copied on
-    the device) must hold the same bits and report the same reductions"""
+    the device; every other sweep in two launches, edge pieces first) must hold the same bits and report the same
+    reductions"""
     from multigrid_amd import lib, slab
     top = hierarchy
     whole = _device(ctx, top)
@@ -110,7 +111,11 @@ def test_two_kernels_and_two_slabs_agree(ctx, hierarchy):
             res[it] = whole.result()
             parts_res = []
             for lv in slabs:
-                lv.sweep(1, red)
+                if it % 2:        # as under a halo exchange: the pieces that hold the edge planes first, then the rest
+                    lv.sweep_part(lib.PART_EDGE, red)
+                    lv.sweep_part(lib.PART_INNER, red)
+                else:
+                    lv.sweep(1, red)
                 parts_res.append(lv.result())
             exchange()
             assert max(r[0] for r in parts_res) == res[it][0]
