@@ -319,20 +319,28 @@ static int do_faces(mgx_level *lv) {
   hipStream_t st = C(lv)->stream;
   const bool z_lo_here = g.z0 == 0, z_hi_here = g.z0 + g.n3 == g.n3g;
   const bool whole = z_lo_here && z_hi_here;
-  for (int face = 0; face < 6; ++face) {
-    const int dim = face / 2, hi = face & 1, bc = lv->bc[face];
+  // the reference fills A0, A1, B0, B1, C0, C1 in this order (t_mg.f90:496-584); the two faces of a direction do not
+  // depend on each other, so each direction is one launch
+  for (int dim = 0; dim < 3; ++dim) {
     const int nd = dim == 0 ? g.n1 : dim == 1 ? g.n2 : g.n3;
-    const int ghost = hi ? nd + 1 : 0;
-    int src = bc == MGX_BC_PERIODIC ? (hi ? 1 : nd) : bc == MGX_BC_NEUMANN ? (hi ? nd : 1) : -1;
+    int ghost[2], src[2];
+    for (int hi = 0; hi < 2; ++hi) {
+      const int bc = lv->bc[2 * dim + hi];
+      ghost[hi] = hi ? nd + 1 : 0;
+      src[hi] = bc == MGX_BC_PERIODIC ? (hi ? 1 : nd) : bc == MGX_BC_NEUMANN ? (hi ? nd : 1) : -1;
+      if (dim == 2) {
+        if ((hi && !z_hi_here) || (!hi && !z_lo_here)) src[hi] = 0;    // inner slab face: owned by the halo exchange
+        if (bc == MGX_BC_PERIODIC && !whole) src[hi] = 0;              // source plane lives on another slab
+      }
+    }
+    if (src[0] == 0 && src[1] == 0) continue;
     if (dim == 2) {
-      if ((hi && !z_hi_here) || (!hi && !z_lo_here)) continue;    // inner slab face: owned by the halo exchange
-      if (bc == MGX_BC_PERIODIC && !whole) continue;              // source plane lives on another slab
-      dim3 grid((g.n1 + 2 + 255) / 256, g.n2 + 2);
-      hipLaunchKernelGGL((k_face<T>), grid, dim3(256), 0, st, V, g, dim, ghost, src, 0, 0);
+      dim3 grid((g.n1 + 2 + 255) / 256, g.n2 + 2, 2);
+      hipLaunchKernelGGL((k_face<T>), grid, dim3(256), 0, st, V, g, dim, ghost[0], src[0], ghost[1], src[1], 0, 0);
     } else {
       const int ext = dim == 0 ? g.n2 + 2 : g.n1 + 2;
-      dim3 grid((ext + 255) / 256, g.n3 + 2);
-      hipLaunchKernelGGL((k_face<T>), grid, dim3(256), 0, st, V, g, dim, ghost, src, 0, g.n3 + 1);
+      dim3 grid((ext + 255) / 256, g.n3 + 2, 2);
+      hipLaunchKernelGGL((k_face<T>), grid, dim3(256), 0, st, V, g, dim, ghost[0], src[0], ghost[1], src[1], 0, g.n3 + 1);
     }
   }
   HIP_TRY(hipGetLastError());

@@ -259,14 +259,19 @@ __global__ __launch_bounds__(256) void k_box_imprint(T *__restrict__ V, const Mg
   }
 }
 
-// one ghost face: dim 0/1/2, side 0 = low / 1 = high.  src < 0: store zero (Dirichlet); otherwise copy
-// the plane with index `src` along dim (periodic / Neumann).  The face spans the full ghosted extent
-// of the other two dimensions, [0,n+1] (z: local planes [zfirst,zlast]).
+// the two ghost faces of one direction (dim 0/1/2; blockIdx.z = 0 low face, 1 high face) in one launch: neither
+// reads what the other writes (the low face copies plane n or 1 into plane 0, the high face plane 1 or n into plane
+// n+1).  src < 0: store zero (Dirichlet); src = 0: leave this face alone (an inner face of a slab); otherwise copy
+// the plane with index `src` along dim (periodic / Neumann).  A face spans the full ghosted extent of the other two
+// dimensions, [0,n+1] (z: local planes [zfirst,zlast]).
 template <typename T>
-__global__ __launch_bounds__(256) void k_face(T *__restrict__ V, const MgxGeom g, const int dim, const int ghost,
-                                              const int src, const int zfirst, const int zlast) {
+__global__ __launch_bounds__(256) void k_face(T *__restrict__ V, const MgxGeom g, const int dim, const int ghost_lo,
+                                              const int src_lo, const int ghost_hi, const int src_hi, const int zfirst,
+                                              const int zlast) {
   const int i = blockIdx.x * blockDim.x + threadIdx.x;
   const int j = blockIdx.y;
+  const int ghost = blockIdx.z ? ghost_hi : ghost_lo, src = blockIdx.z ? src_hi : src_lo;
+  if (src == 0) return;
   int c[3], s[3];
   if (dim == 0) {           // i = y, j = z
     if (i > g.n2 + 1) return;
