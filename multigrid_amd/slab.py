@@ -204,7 +204,7 @@ class SlabLevel:
 
 
 # ----------------------------------------------------------------------------------------------------
-# the whole hierarchy over z slabs: the reference's cycle control (cycle.Solver) with every level decomposed
+# the whole hierarchy over z slabs: the reference's cycle control (cycle.Solver) with the fine levels decomposed
 
 def aligned_splits(levels: List[G.MgGrid], world: int) -> List[List[Tuple[int, int]]]:
     """(z0, n3_local) per rank for every level, coarsest level split evenly and every finer slab the exact
@@ -293,32 +293,157 @@ class SlabDevice(SlabLevel):
         return units / SUM_UNITS
 
 
+class ReplicatedDevice:
+    """a level too thin to be decomposed: every rank holds it whole and does the same work on it.  This is the
+    coarse-level gather of a decomposed solve done as an all-gather: each GPU plays the part of the one that would hold
+    the gathered level (identical kernels, identical results, no communication while the cycle stays on such levels),
+    and nothing has to be scattered on the way back up."""
+
+    def __init__(self, ctx, g: G.MgGrid, level_factory: Optional[Callable] = None):
+        n = [int(v) for v in g.n]
+        make = level_factory if level_factory is not None else ctx.level
+        self.lv = make(g.layer, n, g.dtype, 0, n[2])
+        self.grid, self.z0, self.n3 = g, 0, n[2]
+
+    def set_params(self, sor, a, bc):
+        self.lv.set_params(sor, a, bc)
+
+    def set_boxes(self, *table):
+        self.lv.set_boxes(*table)
+
+    def bring_back(self):
+        self.lv.bring_back()
+
+    def release(self):
+        self.lv.release()
+
+    def close(self):
+        self.lv.close()
+
+    def count_nonconst(self) -> int:
+        return self.lv.count_nonconst()
+
+    def setup(self, init: bool):
+        self.lv.setup(init)
+
+    def refresh_halos(self):
+        pass
+
+    def sweep(self, nsweeps: int = 1, reduce: int = lib.RED_ERR | lib.RED_SUM):
+        self.lv.sweep(int(nsweeps), reduce)
+
+    def result(self):
+        return self.lv.result()
+
+    def abs_sum(self) -> float:
+        return self.lv.abs_sum_limbs() / SUM_UNITS
+
+    def download(self) -> np.ndarray:
+        return self.lv.download()
+
+
 class SlabSolver:
-    """mixin over cycle.Solver: every level is a SlabDevice; restriction and prolongation are local given current
-    halo planes (the slabs are aligned) and are followed by the halo refresh of the level they wrote"""
+    """the reference's cycle control (cycle.Solver) over z slabs: fine levels are SlabDevices, aligned so that
+    restriction and prolongation are local given current halo planes and are followed by the halo refresh of the
+    level they wrote; levels whose slabs would be thinner than `replicate_below` planes are ReplicatedDevices.  Between
+    the last decomposed level and the first replicated one sits a slab of the replicated level's geometry: restriction
+    fills it and the ranks all-gather their planes into their whole copies; prolongation reads it after every rank
+    has copied its planes (and halo planes) out of its own whole copy."""
 
     @staticmethod
     def build(top: G.MgGrid, ctx, rank: int, world: int, group=None, level_factory=None, plane_tensor=None,
-              transfer=None, overlap: bool = True, **kw):
+              transfer=None, overlap: bool = True, replicate_below: int = 16, **kw):
+        import torch.distributed as dist
         from . import cycle
         levels = list(top.levels())
-        splits = aligned_splits(levels, world)
-        by_layer = {g.layer: sp[rank] for g, sp in zip(levels, splits)}
+        first_rep = len(levels)                  # index of the first replicated level
+        if world > 1:
+            for i, g in enumerate(levels):
+                if int(g.n[2]) // world < max(2, int(replicate_below)):
+                    first_rep = i
+                    break
+            while 0 < first_rep < len(levels) and int(levels[first_rep].n[2]) < 2 * world:
+                first_rep -= 1                   # the slab between the two kinds of level needs two planes per rank
+            if first_rep == 0:
+                raise ValueError(f"top level of depth {int(top.n[2])} over {world} ranks: slabs would be thinner than "
+                                 f"{max(2, int(replicate_below))} planes")
+        sliced = levels[:first_rep + 1] if first_rep < len(levels) else levels
+        splits = aligned_splits(sliced, world)
+        by_layer = {g.layer: sp[rank] for g, sp in zip(sliced, splits)}
+        rep_layers = {g.layer for g in levels[first_rep:]}
+        edge_split = splits[-1] if first_rep < len(levels) else None
         do_restrict, do_prolong = transfer if transfer is not None else (lib.restrict, lib.prolong)
+        planes_of = plane_tensor if plane_tensor is not None else device_plane_tensor
+
+        def slab_of(g):
+            z0, n3 = by_layer[g.layer]
+            return SlabDevice(ctx, g, rank, world, z0, n3, group=group, level_factory=level_factory,
+                              plane_tensor=plane_tensor, overlap=overlap)
 
         class _Solver(cycle.Solver):
+            edge = None                          # the slab of the first replicated level's geometry
+
             def make_level(self, g):
-                z0, n3 = by_layer[g.layer]
-                return SlabDevice(ctx, g, rank, world, z0, n3, group=group, level_factory=level_factory,
-                                  plane_tensor=plane_tensor, overlap=overlap)
+                if g.layer in rep_layers:
+                    return ReplicatedDevice(ctx, g, level_factory)
+                return slab_of(g)
+
+            def edge_slab(self, g):
+                if self.edge is None:
+                    self.edge = slab_of(g)
+                    self.edge.set_params(g.sor, [float(v) for v in g.a], g.bc6())
+                    self.edge.set_boxes(*G.box_table(g))
+                return self.edge
+
+            def host_wait(self, dev):
+                if not dev._stream_ordered():    # gloo reads device planes from the host
+                    dev.lv.ctx.sync()
+                    import torch
+                    torch.cuda.synchronize()
 
             def restriction(self, g):
-                do_restrict(g.dev.lv, g.child.dev.lv, g.RES_method)
-                g.child.dev.refresh_halos()
+                c = g.child
+                if g.layer in rep_layers:        # both whole: every rank does the same
+                    do_restrict(g.dev.lv, c.dev.lv, g.RES_method)
+                elif c.layer not in rep_layers:
+                    do_restrict(g.dev.lv, c.dev.lv, g.RES_method)
+                    c.dev.refresh_halos()
+                else:
+                    t = self.edge_slab(c)
+                    t.bring_back()
+                    do_restrict(g.dev.lv, t.lv, g.RES_method)
+                    for r, (z0r, kr) in enumerate(edge_split):      # all-gather of the owned planes
+                        dst = planes_of(c.dev.lv, z0r + 1, kr)
+                        if r == rank:
+                            dst.copy_(planes_of(t.lv, 1, kr))
+                        self.host_wait(t)
+                        dist.broadcast(dst, src=r if group is None else dist.get_global_rank(group, r), group=group)
+                    self.host_wait(t)
+                    c.dev.setup(False)           # grid_setup(child), the end of grid_restriction (t_mg_interp.f90:9-21)
 
             def prolongation(self, g):
-                do_prolong(g.dev.lv, g.parent.dev.lv, g.PRO_method)
-                g.parent.dev.refresh_halos()
+                p = g.parent
+                if p.layer in rep_layers:
+                    do_prolong(g.dev.lv, p.dev.lv, g.PRO_method)
+                elif g.layer not in rep_layers:
+                    do_prolong(g.dev.lv, p.dev.lv, g.PRO_method)
+                    p.dev.refresh_halos()
+                else:
+                    t = self.edge_slab(g)
+                    t.bring_back()
+                    lo, hi = max(-1, -t.z0), min(t.n3 + 2, int(g.n[2]) + 1 - t.z0)   # local planes that exist globally
+                    self.host_wait(t)
+                    planes_of(t.lv, lo, hi - lo + 1).copy_(planes_of(g.dev.lv, t.z0 + lo, hi - lo + 1))
+                    self.host_wait(t)
+                    t.lv.halo_written()
+                    do_prolong(t.lv, p.dev.lv, g.PRO_method)
+                    p.dev.refresh_halos()
+
+            def close(self):
+                if self.edge is not None:
+                    self.edge.close()
+                    self.edge = None
+                super().close()
 
         return _Solver(top, ctx=ctx if ctx is not None else _NoContext(), **kw)
 

@@ -30,7 +30,8 @@ def main():
     stream = torch.cuda.Stream()
     torch.cuda.set_stream(stream)
     ctx = lib.Context(dev, stream.cuda_stream)
-    s = slab.SlabSolver.build(top, ctx, rank, world)
+    below = int(sys.argv[4]) if len(sys.argv) > 4 else 4
+    s = slab.SlabSolver.build(top, ctx, rank, world, replicate_below=below)
     s.mg_gs_cds(method)
     mine = top.dev.download()[1:-1]                      # owned planes, x/y ghosts included
     parts = [None] * world if rank == 0 else None
@@ -39,6 +40,7 @@ def main():
         planes = np.concatenate([p for _, p in sorted(parts, key=lambda t: t[0])], axis=0)
         h = s.history_array()
         np.savez(out, planes=planes, per=np.array([g.itt for g in top.levels()]),
+                 kinds=np.array([type(g.dev).__name__ for g in top.levels()]),
                  **{f"h_{k}": h[k] for k in ("layer", "kind", "itt", "tol", "sum", "err")})
     dist.barrier()
     s.close()

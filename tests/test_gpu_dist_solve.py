@@ -19,8 +19,10 @@ from tests.helpers import DT, config4_input, load, oracle_levels  # noqa: E402
 pytestmark = pytest.mark.gpu
 
 # the last case is the elongated multi-GPU configuration scaled down (x and y stop halving, four levels)
-CASES = [("solve_64_bu", "f64", None), ("solve_64x48x80_v_half", "f32", None), ("solve_80_v", "f64", ("sor 1.8", "sor 1.6")),
-         ("config4", "f64", None)]
+CASES = [("solve_64_bu", "f64", None, 4), ("solve_64x48x80_v_half", "f32", None, 4),
+         ("solve_80_v", "f64", ("sor 1.8", "sor 1.6"), 4), ("config4", "f64", None, 4),
+         # coarse levels replicated on both ranks (slabs thinner than the last number): two of four, one of three
+         ("config4", "f64", None, 100), ("solve_80_v", "f64", ("sor 1.8", "sor 1.6"), 12), ("solve_64_bu", "f32", None, 20)]
 
 
 def _free_port():
@@ -31,8 +33,8 @@ def _free_port():
     return p
 
 
-@pytest.mark.parametrize("name,prec,sub", CASES)
-def test_two_rank_solve_matches_oracle(name, prec, sub, tmp_path):
+@pytest.mark.parametrize("name,prec,sub,below", CASES)
+def test_two_rank_solve_matches_oracle(name, prec, sub, below, tmp_path):
     text = config4_input() if name == "config4" else str(load(f"{name}_{prec}")["input"])
     if sub:
         assert sub[0] in text
@@ -46,10 +48,12 @@ def test_two_rank_solve_matches_oracle(name, prec, sub, tmp_path):
     env = dict(os.environ, PYTHONPATH=ROOT)
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
                         "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
-                        os.path.join(ROOT, "tests", "dist_solve_worker.py"), case, out, "gloo"],
+                        os.path.join(ROOT, "tests", "dist_solve_worker.py"), case, out, "gloo", str(below)],
                        env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, universal_newlines=True, timeout=280)
     assert r.returncode == 0, r.stdout[-3000:]
     d = np.load(out)
+    if below > 4:
+        assert "ReplicatedDevice" in list(d["kinds"]) and str(d["kinds"][0]) == "SlabDevice"
     assert [int(v) for v in d["per"]] == per
     assert len(d["h_itt"]) == len(hist)
     for f in ("layer", "kind", "itt", "tol", "sum", "err"):

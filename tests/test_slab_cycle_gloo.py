@@ -103,7 +103,7 @@ def _read(case):
     return mgio.iomg_read(IO, dtype=case["dtype"]), mgio.read_method(IO)
 
 
-def _worker(rank, world, port, name, outdir):
+def _worker(rank, world, port, name, outdir, replicate_below=4):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -117,7 +117,10 @@ def _worker(rank, world, port, name, outdir):
         V, hist, per = orc.solve(oracle_levels(top), method, case["dtype"], order=orc.ORDER_RB, sum_mode=orc.SUM_EXACT)
         s = slab.SlabSolver.build(top, None, rank, world, level_factory=slab_fake.FakeCycleLevel,
                                   plane_tensor=slab_fake.plane_tensor,
-                                  transfer=(slab_fake.fake_restrict, slab_fake.fake_prolong))
+                                  transfer=(slab_fake.fake_restrict, slab_fake.fake_prolong),
+                                  replicate_below=replicate_below)
+        kinds = [type(g.dev).__name__ for g in top.levels()]
+        open(os.path.join(outdir, f"kinds{rank}"), "w").write(",".join(kinds))
         s.mg_gs_cds(method)
         h = s.history_array()
         assert [g.itt for g in top.levels()] == per, ([g.itt for g in top.levels()], per)
@@ -137,6 +140,20 @@ def _worker(rank, world, port, name, outdir):
 def test_slab_cycle_matches_undivided_solve(name, world, tmp_path):
     mp.spawn(_worker, args=(world, _free_port(), name, str(tmp_path)), nprocs=world, join=True)
     assert all((tmp_path / f"ok{r}").exists() for r in range(world))
+
+
+@pytest.mark.parametrize("name,world,below,kinds", [
+    ("bottom_up_mixed", 2, 30, "SlabDevice,SlabDevice,ReplicatedDevice"),
+    ("bottom_up_mixed", 3, 30, "SlabDevice,ReplicatedDevice,ReplicatedDevice"),
+    ("v_cycle_periodic_z_half", 2, 50, "SlabDevice,ReplicatedDevice,ReplicatedDevice"),
+    ("v_cycle_periodic_z_half", 3, 20, "SlabDevice,SlabDevice,ReplicatedDevice"),
+])
+def test_slab_cycle_with_replicated_coarse_levels(name, world, below, kinds, tmp_path):
+    """levels whose slabs would be thinner than `below` planes live whole on every rank (the coarse-level gather):
+    same history, counts and potential as the undivided solve"""
+    mp.spawn(_worker, args=(world, _free_port(), name, str(tmp_path), below), nprocs=world, join=True)
+    assert all((tmp_path / f"ok{r}").exists() for r in range(world))
+    assert (tmp_path / "kinds0").read_text() == kinds
 
 
 def test_aligned_splits():
