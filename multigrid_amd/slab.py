@@ -63,6 +63,21 @@ def device_plane_tensor(lv: "lib.DeviceLevel", z: int, count: int):
     return t
 
 
+class _StagedTransfers:
+    """transfers of host copies of device planes (gloo): wait() also moves what was received onto the device"""
+
+    def __init__(self, works, received):
+        self.works, self.received = works, received
+
+    def wait(self):
+        import torch
+        for w in self.works:
+            w.wait()
+        for planes, host in self.received:
+            planes.copy_(host)
+        torch.cuda.synchronize()
+
+
 class SlabLevel:
     """one rank's slab of a level + the halo exchange and the all-reduced reductions"""
 
@@ -109,12 +124,29 @@ class SlabLevel:
             return "cpu"
         return self.planes(1, 1).device
 
-    def _run(self, ops):
-        if ops:
-            if not self._stream_ordered():
-                self.lv.ctx.sync()
-            for w in self.dist.batch_isend_irecv(ops):
-                w.wait()
+    def _post(self, spec):
+        """spec: (is_send, planes, peer) in the order both sides of a link agree on; returns objects with .wait().
+        RCCL takes the device planes as they are, ordered on the stream.  gloo moves host memory: device planes are
+        staged through host buffers (the level idle before they are read, received planes copied in by wait())."""
+        if not spec:
+            return []
+        P, d = self.dist.P2POp, self.dist
+        if self._stream_ordered():
+            return d.batch_isend_irecv([P(d.isend if snd else d.irecv, t, peer, self.group) for snd, t, peer in spec])
+        import torch
+        self.lv.ctx.sync()
+        torch.cuda.synchronize()
+        ops, after = [], []
+        for snd, t, peer in spec:
+            h = t.cpu() if snd else torch.empty(t.shape, dtype=t.dtype)
+            ops.append(P(d.isend if snd else d.irecv, h, peer, self.group))
+            if not snd:
+                after.append((t, h))
+        return [_StagedTransfers(d.batch_isend_irecv(ops), after)]
+
+    def _run(self, spec):
+        for w in self._post(spec):
+            w.wait()
 
     def exchange_halos(self):
         """new planes 1,2 -> lower neighbour's n3+1,n3+2; new planes n3-1,n3 -> upper neighbour's -1,0"""
@@ -124,17 +156,15 @@ class SlabLevel:
     def _start_exchange(self):
         if self.world == 1:
             return []
-        if not self._stream_ordered():
-            self.lv.ctx.sync()
-        P, d, ops = self.dist.P2POp, self.dist, []
-        # every rank lists its ops lower-neighbour first: matching order on both sides of a link
+        spec = []
+        # every rank lists its transfers lower-neighbour first: matching order on both sides of a link
         if self.lower is not None:
-            ops.append(P(d.isend, self.planes(1, 2), self.lower, self.group))
-            ops.append(P(d.irecv, self.planes(-1, 2), self.lower, self.group))
+            spec.append((True, self.planes(1, 2), self.lower))
+            spec.append((False, self.planes(-1, 2), self.lower))
         if self.upper is not None:
-            ops.append(P(d.irecv, self.planes(self.n3 + 1, 2), self.upper, self.group))
-            ops.append(P(d.isend, self.planes(self.n3 - 1, 2), self.upper, self.group))
-        return self.dist.batch_isend_irecv(ops) if ops else []
+            spec.append((False, self.planes(self.n3 + 1, 2), self.upper))
+            spec.append((True, self.planes(self.n3 - 1, 2), self.upper))
+        return self._post(spec)
 
     def _exchange_periodic_ghosts(self):
         """grid_setup's periodic C faces (t_mg.f90:553-583): ghost plane 0 = plane n3g, ghost plane n3g+1 = plane 1,
@@ -142,21 +172,21 @@ class SlabLevel:
         if self.world == 1:
             return
         bc = self.grid.bc6()
-        P, d, ops = self.dist.P2POp, self.dist, []
         first, last = 0, self.world - 1
+        spec = []
         if bc[4] == lib.BC_PERIODIC:            # C0: plane 0 on the first rank <- plane n3g on the last
             if self.rank == last:
-                ops.append(P(d.isend, self.planes(self.n3, 1), first, self.group))
+                spec.append((True, self.planes(self.n3, 1), first))
             if self.rank == first:
-                ops.append(P(d.irecv, self.planes(0, 1), last, self.group))
-        self._run(ops)
-        ops = []
+                spec.append((False, self.planes(0, 1), last))
+        self._run(spec)
+        spec = []
         if bc[5] == lib.BC_PERIODIC:            # C1: plane n3g+1 on the last rank <- plane 1 on the first
             if self.rank == first:
-                ops.append(P(d.isend, self.planes(1, 1), last, self.group))
+                spec.append((True, self.planes(1, 1), last))
             if self.rank == last:
-                ops.append(P(d.irecv, self.planes(self.n3 + 1, 1), first, self.group))
-        self._run(ops)
+                spec.append((False, self.planes(self.n3 + 1, 1), first))
+        self._run(spec)
 
     # ---- the level operators -------------------------------------------------------------------
     def setup(self, init: bool):
@@ -416,8 +446,15 @@ class SlabSolver:
                         dst = planes_of(c.dev.lv, z0r + 1, kr)
                         if r == rank:
                             dst.copy_(planes_of(t.lv, 1, kr))
-                        self.host_wait(t)
-                        dist.broadcast(dst, src=r if group is None else dist.get_global_rank(group, r), group=group)
+                        src = r if group is None else dist.get_global_rank(group, r)
+                        if t._stream_ordered():
+                            dist.broadcast(dst, src=src, group=group)
+                        else:                    # gloo moves host memory: stage the device planes
+                            self.host_wait(t)
+                            h = dst.cpu()
+                            dist.broadcast(h, src=src, group=group)
+                            if r != rank:
+                                dst.copy_(h)
                     self.host_wait(t)
                     c.dev.setup(False)           # grid_setup(child), the end of grid_restriction (t_mg_interp.f90:9-21)
 

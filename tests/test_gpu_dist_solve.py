@@ -49,7 +49,7 @@ def test_two_rank_solve_matches_oracle(name, prec, sub, below, tmp_path):
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
                         "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
                         os.path.join(ROOT, "tests", "dist_solve_worker.py"), case, out, "gloo", str(below)],
-                       env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, universal_newlines=True, timeout=280)
+                       env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, universal_newlines=True, timeout=150)
     assert r.returncode == 0, r.stdout[-3000:]
     d = np.load(out)
     if below > 4:
