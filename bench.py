@@ -212,7 +212,7 @@ def main():
     barrier()
     t1 = time.perf_counter()
     e2, s, _ = fetch()
-    dt = torch.tensor([t1 - t0], dtype=torch.float64, device="cuda")
+    dt = torch.tensor([t1 - t0], dtype=torch.float64, device="cuda" if args.backend == "nccl" else "cpu")
     if world > 1:
         dist.all_reduce(dt, op=dist.ReduceOp.MAX)
     wall = float(dt.item())
