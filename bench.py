@@ -238,16 +238,19 @@ def main():
         # rank 0 repeats the same sweeps on the undivided level (it fits one GPU) and compares the reductions of the
         # last sweep bit for bit: red-black results and the exact sum do not depend on the decomposition
         if rank == 0:
-            from multigrid_amd import grid as G
-            whole = ctx.level(top.layer, [int(v) for v in top.n], top.dtype)
-            whole.set_params(top.sor, [float(v) for v in top.a], top.bc6())
-            whole.set_boxes(*G.box_table(top))
-            whole.bring_back()
-            whole.setup(True)
-            whole.sweep(args.warmup + args.steps, lib.RED_ERR | lib.RED_SUM)
-            we2, ws, _ = whole.result()
-            whole.close()
-            out["check"]["undivided"] = {"err_sq_max": we2, "abs_sum": ws, "identical": bool(we2 == e2 and ws == s)}
+            try:
+                from multigrid_amd import grid as G
+                whole = ctx.level(top.layer, [int(v) for v in top.n], top.dtype)
+                whole.set_params(top.sor, [float(v) for v in top.a], top.bc6())
+                whole.set_boxes(*G.box_table(top))
+                whole.bring_back()
+                whole.setup(True)
+                whole.sweep(args.warmup + args.steps, lib.RED_ERR | lib.RED_SUM)
+                we2, ws, _ = whole.result()
+                whole.close()
+                out["check"]["undivided"] = {"err_sq_max": we2, "abs_sum": ws, "identical": bool(we2 == e2 and ws == s)}
+            except Exception as e:        # the measurement stands; the comparison is reported as not done
+                out["check"]["undivided"] = {"error": str(e)}
         barrier()
     tr = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tr):
