@@ -54,8 +54,10 @@ enum { MGX_INTERP_FULL = 1, MGX_INTERP_HALF = 2 };
 enum { MGX_RED_ERR = 1, MGX_RED_SUM = 2 };
 /* the two launches of mgx_level_sweep_part */
 enum { MGX_PART_EDGE = 1, MGX_PART_INNER = 2 };
-/* sweep kernel selection (results are bit-identical; for benchmarking) */
-enum { MGX_KERNEL_AUTO = 0, MGX_KERNEL_TWO_PASS = 1, MGX_KERNEL_FUSED = 2 };
+/* sweep kernel selection (results are bit-identical; for tests and benchmarking): AUTO = the fused kernel, with two
+ * sweeps per pass on the levels where that pays; TWO_PASS = one colour per launch, in place; FUSED = black and red
+ * in one pass, one sweep per pass everywhere; PAIR = as FUSED, two sweeps per pass wherever that kernel applies */
+enum { MGX_KERNEL_AUTO = 0, MGX_KERNEL_TWO_PASS = 1, MGX_KERNEL_FUSED = 2, MGX_KERNEL_PAIR = 3 };
 
 const char *mgx_last_error(void);
 const char *mgx_version(void);

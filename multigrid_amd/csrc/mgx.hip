@@ -10,8 +10,9 @@
 #include <string>
 #include <vector>
 
+#define MGX_MAIN_UNIT
 #include "mgx_kernels.hpp"
-#include "mgx_fused.hpp"
+#include "mgx_plan.hpp"
 
 // ------------------------------------------------------------------------------------------------
 // errors
@@ -42,6 +43,8 @@ static int fail(int code, const char *fmt, ...) {
 
 extern "C" const char *mgx_last_error(void) { return g_err; }
 extern "C" const char *mgx_version(void) { return "mgx 0.1 (gfx950)"; }
+
+static int mgx_pair_pass = -1;   // 0: never two sweeps per pass, 1: wherever the kernel applies, -1: where it pays (default)
 
 // ------------------------------------------------------------------------------------------------
 // objects
@@ -79,6 +82,7 @@ struct mgx_level {
   long long count_cache = -1;
   u64 *d_res = nullptr;        // MGX_RES_WORDS words
   MgxFusedPlan plan;           // tile lists of the fused sweep (rebuilt when the boxes change)
+  MgxFusedPlan plan2;          // tile lists of the two-sweeps-per-pass kernel
   std::vector<struct MgxTransferPlan *> transfers;   // index tables of transfers INTO this level, by source geometry
 };
 
@@ -137,6 +141,7 @@ extern "C" int mgx_ctx_create(int device, void *stream, mgx_ctx **out) {
   if (const char *e = getenv("MGX_FUSED_NW")) mgx_fused_nw = atoi(e);
   if (const char *e = getenv("MGX_FUSED_ZC")) mgx_fused_zc = atoi(e);
   if (const char *e = getenv("MGX_FUSED_TAIL")) mgx_fused_tail = atoi(e);
+  if (const char *e = getenv("MGX_PAIR_PASS")) mgx_pair_pass = atoi(e);   // 0 off, 1 on every level the kernel takes
   if (stream) {
     c->stream = (hipStream_t)stream;
   } else {
@@ -178,7 +183,7 @@ extern "C" int mgx_ctx_sync(mgx_ctx *ctx) {
 
 extern "C" int mgx_ctx_set_kernel(mgx_ctx *ctx, int which) {
   if (!ctx) return fail(MGX_EINVAL, "mgx_ctx_set_kernel: ctx is NULL");
-  if (which < MGX_KERNEL_AUTO || which > MGX_KERNEL_FUSED) return fail(MGX_EINVAL, "mgx_ctx_set_kernel: %d", which);
+  if (which < MGX_KERNEL_AUTO || which > MGX_KERNEL_PAIR) return fail(MGX_EINVAL, "mgx_ctx_set_kernel: %d", which);
   ctx->kernel = which;
   return MGX_OK;
 }
@@ -242,6 +247,7 @@ extern "C" int mgx_level_destroy(mgx_level *lv) {
   (void)hipFree(lv->d_res);
   if (lv->d_boxes) (void)hipFree(lv->d_boxes);
   if (lv->plan.d_tiles) (void)hipFree(lv->plan.d_tiles);
+  if (lv->plan2.d_tiles) (void)hipFree(lv->plan2.d_tiles);
   for (MgxTransferPlan *t : lv->transfers) { (void)hipFree(t->d_tab); delete t; }
   delete lv;
   return MGX_OK;
@@ -306,6 +312,7 @@ extern "C" int mgx_level_set_boxes(mgx_level *lv, int32_t nbox, const int32_t *p
   lv->nbox = nbox;
   lv->count_cache = -1;
   lv->plan.valid = false;
+  lv->plan2.valid = false;
   return MGX_OK;
 }
 
@@ -413,21 +420,49 @@ static int sync_shell(mgx_level *lv) {
   return MGX_OK;
 }
 
+// Two sweeps per pass pay on levels whose z chunks are long against the six extra steps and eight extra planes of a
+// chunk and whose tile rows are wide enough to fill the 128 x 22 tiles: undivided levels from 96 x 44 x 64 cells on.
+template <typename T>
+static bool pair_pass_wanted(const mgx_level *lv) {
+  const MgxGeom &g = lv->g;
+  const int k = lv->ctx->kernel;
+  if (mgx_pair_pass == 0 || k == MGX_KERNEL_FUSED || g.n3 != g.n3g || !mgx_fused_supported<T>(g, lv->nbox)) return false;
+  if (mgx_pair_pass == 1 || k == MGX_KERNEL_PAIR) return true;
+  return g.n1 >= 96 && g.n2 >= 44 && g.n3 >= 64;
+}
+
 template <typename T>
 static int do_sweeps(mgx_level *lv, int nsweeps, int reduce) {
   const MgxGeom &g = lv->g;
   int which = C(lv)->kernel;
   if (which == MGX_KERNEL_AUTO) which = mgx_fused_supported<T>(g, lv->nbox) ? MGX_KERNEL_FUSED : MGX_KERNEL_TWO_PASS;
+  if (which == MGX_KERNEL_PAIR) which = MGX_KERNEL_FUSED;
   if (which == MGX_KERNEL_FUSED && !mgx_fused_supported<T>(g, lv->nbox))
     return fail(MGX_ELIMIT, "mgx_level_sweep: the fused kernel handles at most %d boxes", MGX_MAX_FUSED_BOXES);
   for (int s = 0; s < nsweeps; ++s) {
+    if (which == MGX_KERNEL_FUSED && s + 2 <= nsweeps && pair_pass_wanted<T>(lv)) {
+      // two sweeps in one pass over the field (gs_V's legs run their sweeps back to back, m_gs_CDS.F90:240-242)
+      const int red = (s + 2 == nsweeps) ? reduce : 0;
+      if (red) TRY(reset_result(lv));
+      TRY(sync_shell<T>(lv));
+      if (!lv->plan2.valid && mgx_fused_make_plan(lv->plan2, g, lv->boxes, C(lv)->stream, 2) != 0)
+        return fail(MGX_EHIP, "mgx_level_sweep: could not build the tile lists of the two-sweep kernel");
+      if (mgx_tb2_launch(lv->plan2, (const T *)lv->buf[lv->cur], (T *)lv->buf[1 - lv->cur], g,
+                                                    make_params<T>(lv), lv->d_boxes, lv->nbox, red, lv->d_res,
+                                                    C(lv)->stream) != 0)
+        return fail(MGX_EHIP, "mgx_level_sweep: two-sweep kernel launch configuration failed");
+      HIP_TRY(hipGetLastError());
+      lv->cur = 1 - lv->cur;
+      ++s;
+      continue;
+    }
     const int red = (s == nsweeps - 1) ? reduce : 0;
     if (red) TRY(reset_result(lv));
     if (which == MGX_KERNEL_FUSED) {
       TRY(sync_shell<T>(lv));
       if (!lv->plan.valid && mgx_fused_make_plan(lv->plan, g, lv->boxes, C(lv)->stream) != 0)
         return fail(MGX_EHIP, "mgx_level_sweep: could not build the tile lists of the fused kernel");
-      if (mgx_fused_launch<T>(lv->plan, 0, (const T *)lv->buf[lv->cur], (T *)lv->buf[1 - lv->cur], g, make_params<T>(lv),
+      if (mgx_fused_launch(lv->plan, 0, (const T *)lv->buf[lv->cur], (T *)lv->buf[1 - lv->cur], g, make_params<T>(lv),
                               lv->d_boxes, lv->nbox, red, lv->d_res, C(lv)->stream) != 0)
         return fail(MGX_EHIP, "mgx_level_sweep: fused kernel launch configuration failed");
       HIP_TRY(hipGetLastError());
@@ -474,7 +509,7 @@ static int do_sweep_part(mgx_level *lv, int part, int reduce) {
     TRY(sync_shell<T>(lv));
     if (!lv->plan.valid && mgx_fused_make_plan(lv->plan, g, lv->boxes, C(lv)->stream) != 0)
       return fail(MGX_EHIP, "mgx_level_sweep_part: could not build the tile lists of the fused kernel");
-    if (mgx_fused_launch<T>(lv->plan, 1, (const T *)lv->buf[lv->cur], (T *)lv->buf[1 - lv->cur], g, make_params<T>(lv),
+    if (mgx_fused_launch(lv->plan, 1, (const T *)lv->buf[lv->cur], (T *)lv->buf[1 - lv->cur], g, make_params<T>(lv),
                             lv->d_boxes, lv->nbox, reduce, lv->d_res, C(lv)->stream) != 0)
       return fail(MGX_EHIP, "mgx_level_sweep_part: fused kernel launch configuration failed");
     HIP_TRY(hipGetLastError());
@@ -482,7 +517,7 @@ static int do_sweep_part(mgx_level *lv, int part, int reduce) {
     lv->inner_pending = true;
   } else {
     if (!lv->inner_pending) return fail(MGX_ESTATE, "mgx_level_sweep_part: the inner part follows the edge part");
-    if (mgx_fused_launch<T>(lv->plan, 2, (const T *)lv->buf[1 - lv->cur], (T *)lv->buf[lv->cur], g, make_params<T>(lv),
+    if (mgx_fused_launch(lv->plan, 2, (const T *)lv->buf[1 - lv->cur], (T *)lv->buf[lv->cur], g, make_params<T>(lv),
                             lv->d_boxes, lv->nbox, reduce, lv->d_res, C(lv)->stream) != 0)
       return fail(MGX_EHIP, "mgx_level_sweep_part: fused kernel launch configuration failed");
     HIP_TRY(hipGetLastError());

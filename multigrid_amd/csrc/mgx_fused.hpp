@@ -36,6 +36,7 @@
 #pragma once
 
 #include "mgx_kernels.hpp"
+#include "mgx_plan.hpp"
 
 #ifdef MGX_ABLATE_BARRIER
 #define MGX_SYNC() __builtin_amdgcn_s_waitcnt(0xc07f)
@@ -57,8 +58,6 @@ template <> struct MgxVec2<float> { typedef float2 type; };
 #define MGX_F_OWN0 64     // component 0 counts in this tile's reductions
 #define MGX_F_OWN1 128
 
-#define MGX_MAX_FUSED_BOXES 32
-
 template <typename T>
 struct MgxBoxLds {           // per-block copy of what the box logic needs
   unsigned zsets[2][4];      // [step parity][plane k-1, k, k+1, unused]
@@ -67,7 +66,7 @@ struct MgxBoxLds {           // per-block copy of what the box logic needs
   // with rho != 1) as their first box, the others rho = 1: made once per block with the reference's arithmetic
   // (rho*a, sequential sum, six divisions, m_gs_CDS.F90:729-735); entry [0][0] is the box-free cell
   T wtab[2][64][6];
-  uint4 xq[64 + 2];          // X sets of positions xs-1 .. xs+2 around staged pair column pc
+  uint4 xq[64 + 4];          // X sets of positions xs-1 .. xs+2 around staged pair column pc (up to two halo pairs a side)
   uint4 yq[64];              // Y sets of rows y-1, y, y+1 around staged row r (rows past the tile: empty)
 };
 
@@ -595,137 +594,7 @@ __global__ __launch_bounds__((NW + 1) * 64) void k_fused_sweep(const T *__restri
 }
 
 // ------------------------------------------------------------------------------------------------
-// host side
-
-struct MgxTileList {             // segment sizes, each padded to a multiple of 8, and where the list starts
-  int n_fast = 0, n_const = 0, n_box = 0;
-  int offset = 0;                // entry (3 ints each) in MgxFusedPlan::d_tiles: n_box entries, n_const, n_fast; -1 = padding
-};
-
-struct MgxFusedPlan {            // per level: tile decomposition and the tile lists (device)
-  int ty = 0, nw = 4, ZC = 0, ntx = 0, nty = 0, nzc = 0;
-  // [0] every tile; [1] the tiles of the z chunks that hold planes 1, 2, n3-1, n3 (the planes a z slab sends to
-  // its neighbours); [2] the others
-  MgxTileList list[3];
-  int *d_tiles = nullptr;
-  bool valid = false;
-};
-
-static int mgx_fused_ty = 0;     // tile height override (0 = automatic), settable for benchmarking
-static int mgx_fused_nw = 0;     // row waves per block override (4 or 8)
-#define MGX_EDGE_PLANES 8        /* planes at either end of a slab swept ahead of the halo exchange */
-static int mgx_fused_zc = 0;     // z chunk override (0 = automatic)
-static int mgx_fused_tail = -1;  // percent of the box-free chunks cut into halves, and half as many again into quarters (-1 = automatic)
-
-// (re)build the plan: which tiles can any box reach?  A tile asks about cells of its footprint grown by
-// one and about their neighbours, i.e. positions grown by two, on planes zc0-2 .. zc1+2.
-static int mgx_fused_make_plan(MgxFusedPlan &pl, const MgxGeom &g, const std::vector<MgxBox> &boxes, hipStream_t st) {
-  constexpr int TXP = 64;
-  if (pl.d_tiles) { (void)hipFree(pl.d_tiles); pl.d_tiles = nullptr; }
-  pl.valid = false;
-  // 128 x 20 tiles on 8 row waves measured fastest on large levels; small levels take the small tile
-  if (g.n1 >= 96 && g.n2 >= 40) { pl.ty = 20; pl.nw = 8; } else { pl.ty = 8; pl.nw = 4; }
-  if (mgx_fused_ty > 0) {
-    const int want = mgx_fused_ty * 100 + mgx_fused_nw;
-    if (want == 804 || want == 1208 || want == 2008) { pl.ty = mgx_fused_ty; pl.nw = mgx_fused_nw; }
-  }
-  pl.ntx = (g.n1 + 2 * TXP - 1) / (2 * TXP);
-  pl.nty = (g.n2 + pl.ty - 1) / pl.ty;
-  // z chunk: at least three rounds of blocks on 256 compute units (tiles differ in cost: the rounds even that
-  // out), but no shorter than 32 planes: every chunk start re-reads four planes (measured at 512^3: 64 planes
-  // 2 % faster than 32 with boxes and reductions, within noise otherwise)
-  int ZC = g.n3;
-  const long long per_chunk = (long long)pl.ntx * pl.nty;
-  while (ZC > 32 && per_chunk * ((g.n3 + ZC - 1) / ZC) < 768) ZC = (ZC + 1) / 2;
-  // small levels live in the caches and their sweeps are bound by the length of the march: shorter chunks until
-  // the blocks fill the compute units about twice (measured: 256^3 best at 16 planes, 128^3 and below at 4)
-  while (ZC > 4 && per_chunk * ((g.n3 + ZC - 1) / ZC) < 400) ZC = (ZC + 1) / 2;
-  if (mgx_fused_zc > 0) ZC = std::min(mgx_fused_zc, g.n3);
-  pl.ZC = ZC;
-  pl.nzc = (g.n3 + ZC - 1) / ZC;
-  const long long ntile = per_chunk * pl.nzc;
-  if (ntile > 0x7fffffffLL) return -1;
-  // Blocks are dispatched in index order, block b to XCD b mod 8, one block per compute unit.  Chunks that differ
-  // in cost must therefore come in groups of 8 equal ones (or an XCD that got the long ones holds up the
-  // dispatch of all), and the last blocks to start decide when the sweep ends: of the box-free chunks of a large
-  // level, 12 % are cut into halves and 6 % into quarters, dispatched last in that order, so that the compute
-  // units run dry within a quarter chunk of each other (measured at 512^3: 2 % to 6 % per sweep; larger
-  // fractions lose it again to the four planes every piece reads ahead of its first).
-  struct Piece { int col, z0, z1; };
-  int tail = mgx_fused_tail >= 0 ? mgx_fused_tail : (ZC >= 32 && ntile >= 512 ? 12 : 0);
-  if (tail > 60) tail = 60;
-  std::vector<int> all;
-  auto classify = [&](int tx, int ty, int a, int b) {
-    const int x0 = 1 + tx * 2 * TXP - 2, x1 = 1 + (tx + 1) * 2 * TXP + 1;
-    const int y0 = 1 + ty * pl.ty - 2, y1 = 1 + (ty + 1) * pl.ty + 1;
-    const int z0 = a - 2 + g.z0, z1 = b + 2 + g.z0;
-    int c = 0;
-    for (const MgxBox &bb : boxes)
-      if (bb.lo[0] <= x1 && x0 <= bb.hi[0] && bb.lo[1] <= y1 && y0 <= bb.hi[1] && bb.lo[2] <= z1 && z0 <= bb.hi[2])
-        c = std::max(c, bb.rho_is_one ? 1 : 2);
-    return c;
-  };
-  // the groups of the whole level: [0] rho boxes, [1] constant boxes only, [2] box-free whole, [3] halves, [4] quarters
-  std::vector<Piece> grp[5];
-  {
-    std::vector<Piece> fast;
-    // z ranges: chunks of ZC planes; a slab of a decomposed level first gets its lowest and highest MGX_EDGE_PLANES
-    // planes as ranges of their own: they hold the planes the neighbours wait for, and the part of the sweep that
-    // must finish before the exchange starts (MGX_PART_EDGE) is then a single short round of blocks
-    std::vector<std::pair<int, int>> zr;
-    const bool carve = g.n3 != g.n3g && g.n3 >= 4 * MGX_EDGE_PLANES && ZC > MGX_EDGE_PLANES;
-    const int zfirst = carve ? 1 + MGX_EDGE_PLANES : 1, zlast = carve ? g.n3 - MGX_EDGE_PLANES : g.n3;
-    if (carve) zr.push_back({1, MGX_EDGE_PLANES});
-    for (int a = zfirst; a <= zlast; a += ZC) zr.push_back({a, std::min(a + ZC - 1, zlast)});
-    if (carve) zr.push_back({zlast + 1, g.n3});
-    for (size_t iz = 0; iz < zr.size(); ++iz) {
-      const int zc0 = zr[iz].first, zc1 = zr[iz].second;
-      const bool carved = carve && (iz == 0 || iz + 1 == zr.size());
-      for (int ty = 0; ty < pl.nty; ++ty)
-        for (int tx = 0; tx < pl.ntx; ++tx) {
-          const int c = classify(tx, ty, zc0, zc1);
-          (c == 2 ? grp[0] : c == 1 ? grp[1] : carved ? grp[4] : fast).push_back({ty * pl.ntx + tx, zc0, zc1});
-        }
-    }
-    const size_t nq = fast.size() * (size_t)tail / 200, nh = fast.size() * (size_t)tail / 100;
-    const size_t nwhole = fast.size() - std::min(fast.size(), nq + nh);
-    for (size_t i = 0; i < fast.size(); ++i) {
-      const Piece &f = fast[i];
-      const int parts = i < nwhole ? 1 : i < nwhole + nh ? 2 : 4;
-      const int len = f.z1 - f.z0 + 1, plen = std::max(4, (len + parts - 1) / parts);
-      if (parts == 1 || len <= plen) { grp[2].push_back(f); continue; }
-      for (int a = f.z0; a <= f.z1; a += plen) grp[parts == 2 ? 3 : 4].push_back({f.col, a, std::min(a + plen - 1, f.z1)});
-    }
-  }
-  for (int sel = 0; sel < 3; ++sel) {
-    MgxTileList &tl = pl.list[sel];
-    tl.offset = (int)all.size() / 3;
-    int count[3] = {0, 0, 0};
-    for (int gi = 0; gi < 5; ++gi) {
-      std::vector<Piece> v;
-      for (const Piece &q : grp[gi]) {
-        const bool edge = q.z0 <= 2 || q.z1 >= g.n3 - 1;     // holds plane 1, 2, n3-1 or n3
-        if (sel == 0 || (sel == 1) == edge) v.push_back(q);
-      }
-      while (v.size() % 8) v.push_back({-1, 0, 0});
-      const size_t per = v.size() / 8;
-      for (size_t i = 0; i < v.size(); ++i) {                // block i of the group runs on XCD i mod 8: give every
-        const Piece &q = v[(i & 7) * per + (i >> 3)];        // XCD a contiguous run of the group (neighbouring tiles)
-        all.push_back(q.col); all.push_back(q.z0); all.push_back(q.z1);
-      }
-      count[gi == 0 ? 0 : gi == 1 ? 1 : 2] += (int)v.size();
-    }
-    tl.n_box = count[0];
-    tl.n_const = count[1];
-    tl.n_fast = count[2];
-  }
-  if (all.empty()) all.insert(all.end(), {-1, 0, 0});
-  if (hipMalloc((void **)&pl.d_tiles, sizeof(int) * all.size()) != hipSuccess) return -1;
-  if (hipMemcpyAsync(pl.d_tiles, all.data(), sizeof(int) * all.size(), hipMemcpyHostToDevice, st) != hipSuccess) return -1;
-  if (hipStreamSynchronize(st) != hipSuccess) return -1;     // `all` goes out of scope
-  pl.valid = true;
-  return 0;
-}
+// launch (host)
 
 template <typename T, int TY, int NW>
 static int mgx_fused_launch_cfg(const MgxFusedPlan &pl, int part, const T *src, T *dst, const MgxGeom &g,
@@ -745,16 +614,8 @@ static int mgx_fused_launch_cfg(const MgxFusedPlan &pl, int part, const T *src, 
   return 0;
 }
 
-// the box body keeps one bit per box in 32-bit sets
 template <typename T>
-static bool mgx_fused_supported(const MgxGeom &g, int nbox) {
-  // pairs are addressed by 32-bit byte offsets inside a plane
-  return g.n1 >= 1 && g.n2 >= 1 && g.n3 >= 1 && nbox <= MGX_MAX_FUSED_BOXES &&
-         (g.pz + g.front) * (long long)sizeof(T) < 0x7fffffffLL;
-}
-
-template <typename T>
-static int mgx_fused_launch(const MgxFusedPlan &pl, int part, const T *src, T *dst, const MgxGeom &g,
+static int mgx_fused_launch_t(const MgxFusedPlan &pl, int part, const T *src, T *dst, const MgxGeom &g,
                             const MgxSweepParams<T> &p, const MgxBox *bx, int nb, int reduce, u64 *res, hipStream_t st) {
   switch (pl.ty * 100 + pl.nw) {
     case 1208: return mgx_fused_launch_cfg<T, 12, 8>(pl, part, src, dst, g, p, bx, nb, reduce, res, st);

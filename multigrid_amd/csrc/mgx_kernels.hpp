@@ -64,6 +64,8 @@ __device__ inline void mgx_block_commit(double err, u64 lo, u64 hi, unsigned ovf
 }
 
 // fold the replicas into record 0 (max of word 0, sums of words 1..5); one block of MGX_RES_SLOTS threads
+// (not a template: defined in the translation unit that launches it)
+#ifdef MGX_MAIN_UNIT
 __global__ __launch_bounds__(MGX_RES_SLOTS) void k_fold_result(u64 *__restrict__ res) {
   __shared__ u64 sh[MGX_RES_SLOTS / 64][6];
   const u64 *mine = res + MGX_RES_WORDS * (1 + threadIdx.x);
@@ -86,6 +88,7 @@ __global__ __launch_bounds__(MGX_RES_SLOTS) void k_fold_result(u64 *__restrict__
     for (int k = 0; k < 5; ++k) res[1 + k] = dd[k];
   }
 }
+#endif
 
 // ------------------------------------------------------------------------------------------------
 // box predicates (t_mg.f90:634-710) on the device table; coordinates are GLOBAL

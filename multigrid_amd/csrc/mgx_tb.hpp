@@ -1,0 +1,438 @@
+// Temporally blocked red-black sweeps: NS full sweeps of gs (m_gs_CDS.F90:317-345) — 2*NS half-sweeps, black
+// (odd x+y+z) first — in ONE pass over the field, out of place (src -> dst).  gs_V runs `steps` sweeps back to
+// back with no host decision in between (m_gs_CDS.F90:240-242, 271-273): a pass of NS = 2 reads and writes every
+// cell once for two sweeps.
+//
+// Pipeline.  A block owns an output tile of 128 x TY cells and marches a z chunk.  Half-sweep s (s = 0 .. L,
+// L = 2 NS - 1) lags s planes behind the first: at step k stage s updates its colour on plane k - s, on the tile
+// grown by L - s cells in x, y and z (the ring is recomputed by the neighbouring tiles; only the last stage works
+// on the tile proper and stores it).  A half-sweep reads the other colour as the half-sweep before it left it:
+//   in-plane neighbours  from LDS: stage s - 1 wrote plane k - s there one step earlier
+//   plane above          from the lane's own registers: stage s - 1 updated plane k - s + 1 earlier in this step
+//   plane below          from the lane's own registers: plane k - s - 1, which stage s + 1 has not yet touched
+// Every LDS array (one per stage: the other colour of the stage's plane) is double-buffered by step parity, so a
+// stage only reads what was written before the step's single barrier.
+//
+// Lanes.  As in the one-sweep kernel a lane owns x-pairs (odd cell, even cell: 16 bytes in fp64, loaded and stored
+// whole) and keeps the z column of each pair in registers: planes k+1 .. k-L plus the planes in flight.  Row waves
+// own rows w, w + NW, ... of the staged region (64 pairs of the tile proper per row), one more wave owns the
+// 2 NS halo pairs of every row.  Rows of a wave share the parity of y, and the step loop is unrolled twice, so
+// "which cell of the pair has the colour of this step" is a compile-time constant (all stages of a step update
+// the same position of their pairs: the colour alternates with the stage and the position of a colour with the
+// plane).  The register window moves down one plane per step by copies; only the sets that receive the loads
+// alternate by step parity, so that no copy waits for a load just issued.
+//
+// Boxes (t_mg.f90:634-710): bit sets and per-cell codes exactly as in the one-sweep kernel (mgx_cell_code,
+// mgx_cell_from_code); a lane keeps the codes of both cells of its pairs for the planes k .. k-L and takes the
+// codes of a new plane from plane k-2 when the three Z sets around them are equal.
+#pragma once
+
+#include <type_traits>
+
+#include "mgx_fused.hpp"
+
+template <int R>
+__device__ __forceinline__ void mgx_sum_items(const double (&a)[R], double &fh, double &fl2, u64 &slo, u64 &shi,
+                                              unsigned &ovf) {
+  // a[j] already has its high word cleared where the cell does not count (adds exactly nothing)
+  unsigned top = 0u;
+#pragma unroll
+  for (int j = 0; j < R; ++j) {
+    const unsigned h = (unsigned)__double2hiint(a[j]);
+    top = h > top ? h : top;
+  }
+  if (__builtin_expect(__any(top >= MGX_FAST_SUM_LIMIT_HI), 0)) {
+#pragma unroll
+    for (int j = 0; j < R; ++j) mgx_exact_add_nb(slo, shi, a[j], ovf);
+  } else {
+#pragma unroll
+    for (int j = 0; j < R; ++j) mgx_fast_sum_add(fh, fl2, a[j]);
+  }
+}
+
+// |v| where the cell counts, else a value below 2^-1022 (high word cleared)
+__device__ __forceinline__ double mgx_abs_if(const double v, const bool cond) {
+  const unsigned h = cond ? ((unsigned)__double2hiint(v) & 0x7fffffffu) : 0u;
+  return __hiloint2double((int)h, __double2loint(v));
+}
+
+template <typename T, int NS, int TY, int BOXES, int NW, int DF, int P0, bool HALO>
+__device__ __forceinline__ void mgx_tb_body(const T *__restrict__ src, T *__restrict__ dst, const MgxGeom &g,
+                                            const MgxSweepParams<T> &p, const MgxBox *__restrict__ bx, const int nb,
+                                            const int tx0, const int ty0, const int zc0, const int zc1,
+                                            const int reduce, u64 *__restrict__ res, T *__restrict__ lds,
+                                            MgxBoxLds<T> *__restrict__ bl) {
+  typedef typename MgxVec2<T>::type V2;
+  constexpr int TXP = 64;
+  constexpr int HP = NS;                   // halo pairs on either side of a row
+  constexpr int LP = TXP + 2 * HP;         // pairs per staged row
+  constexpr int LR = TY + 4 * NS;          // staged rows
+  constexpr int PL = LP * (LR + 2);        // elements of one LDS array (one guard row above and below)
+  constexpr int RW = LR / NW;
+  constexpr int R = HALO ? 2 : RW;         // items (pairs) of a lane
+  constexpr int L = 2 * NS - 1;            // last stage
+  constexpr int NP = L + 2;                // register sets of planes k+1 .. k-L
+  static_assert(LR % NW == 0 && NW % 2 == 0, "rows of a wave must share the parity of y");
+  static_assert(LR % 2 == 0 && (LR / 2) * 2 * HP <= 64, "the halo pairs of two rows per lane must fit one wave");
+  static_assert(DF == 1 || DF == 2, "one or two planes in flight");
+  static_assert(R <= 5, "codes of at most five pairs per lane");
+  auto A = [&](int stage, int buf, int i) -> T & { return lds[(stage * 2 + buf) * PL + i]; };
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+
+  // ---- items: branch-free per item; what must not be touched is masked by value selects, its loads go to the
+  // first element of the plane and its LDS writes to the guard row; only the global stores are predicated ----
+  int li[R];
+  unsigned fl[R];                          // bit 2 s + c: stage s may update cell c; bits 16, 17: cell counts in the reductions
+  unsigned gob[R];                         // byte offset of the pair inside a plane
+  bool st[R];
+  int rr[5] = {0, 0, 0, 0, 0};
+  int pcs = 0;
+#pragma unroll
+  for (int j = 0; j < R; ++j) {
+    int r, pc;
+    bool valid;
+    if (!HALO) { r = wave + NW * j; pc = HP + lane; valid = true; }
+    else {
+      const int sel = lane % (2 * HP);
+      r = 2 * (lane / (2 * HP)) + j;
+      pc = sel < HP ? sel : LP - 2 * HP + sel;
+      valid = lane < (LR / 2) * 2 * HP;
+    }
+    const int y = ty0 - 2 * NS + r, xs = tx0 - 2 * NS + 2 * pc;
+    unsigned f = 0u;
+    bool ld = false, store = false;
+    if (valid && y >= 0 && y <= g.n2 + 1 && xs >= -1 && xs <= g.n1 + 1) {
+      ld = true;
+      const bool yin = y >= 1 && y <= g.n2;
+#pragma unroll
+      for (int s = 0; s <= L; ++s) {
+        const int gs = L - s;
+        const bool rok = yin && r >= s + 1 && r <= LR - 2 - s;
+#pragma unroll
+        for (int c = 0; c < 2; ++c) {
+          const int x = xs + c;
+          if (rok && x >= 1 && x <= g.n1 && x >= tx0 - gs && x <= tx0 + 2 * TXP - 1 + gs) f |= 1u << (2 * s + c);
+        }
+      }
+      const bool proper = yin && r >= 2 * NS && r <= LR - 1 - 2 * NS && pc >= HP && pc < HP + TXP;
+      if (proper && xs >= 1 && xs <= g.n1) { store = true; f |= 1u << 16; }
+      if (proper && xs + 1 >= 1 && xs + 1 <= g.n1) f |= 1u << 17;
+    }
+    li[j] = ld ? (r + 1) * LP + pc : 0;
+    fl[j] = f;
+    gob[j] = (unsigned)((ld ? g.front + (long long)(xs - 1) + (long long)g.px * y : g.front) * (long long)sizeof(T));
+    st[j] = store;
+    rr[j] = r;
+    pcs = pc;
+  }
+
+  // ---- box tables of the block (row waves) and the z range of "my" box (every wave: lane = box) ----
+  unsigned cmask = 0u, rmask = 0u, tb0 = 0u, tb1 = 0u;
+  int blo2 = 1, bhi2 = 0;
+  if (BOXES) {
+    for (int b = 0; b < nb; ++b) {
+      cmask |= bx[b].constant ? (1u << b) : 0u;
+      rmask |= bx[b].rho_is_one ? 0u : (1u << b);
+    }
+    if (lane < nb) { blo2 = bx[lane].lo[2]; bhi2 = bx[lane].hi[2]; }
+    tb0 = rmask & (0u - rmask);
+    tb1 = (rmask ^ tb0) & (0u - (rmask ^ tb0));
+    if (!HALO && threadIdx.x <= MGX_MAX_FUSED_BOXES) bl->rho[threadIdx.x] = threadIdx.x < nb ? (T)bx[threadIdx.x].rho : (T)1;
+    if (!HALO && threadIdx.x < LP + 64) {
+      const bool isx = threadIdx.x < LP;
+      const int pos = isx ? tx0 - 2 * NS + 2 * (int)threadIdx.x - 1 : ty0 - 2 * NS + ((int)threadIdx.x - LP) - 1;
+      unsigned q4[4] = {0u, 0u, 0u, 0u};
+      for (int b = 0; b < nb && (isx || (int)threadIdx.x - LP < LR); ++b) {
+        const int lo = isx ? bx[b].lo[0] : bx[b].lo[1], hi = isx ? bx[b].hi[0] : bx[b].hi[1];
+#pragma unroll
+        for (int d = 0; d < 4; ++d) q4[d] |= (lo <= pos + d && pos + d <= hi) ? (1u << b) : 0u;
+      }
+      const uint4 v4 = make_uint4(q4[0], q4[1], q4[2], isx ? q4[3] : 0u);
+      if (isx) bl->xq[threadIdx.x] = v4; else bl->yq[threadIdx.x - LP] = v4;
+    }
+    if (BOXES == 2 && !HALO && threadIdx.x >= 128 && threadIdx.x < 256) {
+      const int t = (threadIdx.x - 128) >> 6, m = threadIdx.x & 63;
+      const unsigned tb = t ? tb1 : tb0;
+      const T rb = tb ? (T)bx[__ffs((int)tb) - 1].rho : (T)1;
+      T r[6];
+#pragma unroll
+      for (int i = 0; i < 6; ++i) r[i] = (((m >> i) & 1) ? rb : (T)1) * p.a[i >> 1];
+      T s = r[0];
+      s = s + r[1]; s = s + r[2]; s = s + r[3]; s = s + r[4]; s = s + r[5];
+#pragma unroll
+      for (int i = 0; i < 6; ++i) bl->wtab[t][m][i] = r[i] / s;
+    }
+  }
+  auto zset = [&](int zglob) -> unsigned {       // boxes whose z range holds the global plane
+    return BOXES ? (unsigned)__ballot(blo2 <= zglob && zglob <= bhi2) : 0u;
+  };
+
+  const long long pzl = g.pz;
+  const int k0 = zc0 - L;                        // first step: stage 0 on the lowest plane of the grown chunk
+  const int zmin = -1, zmax = g.n3 + 2;          // planes of the allocation
+  auto fetch = [&](V2 (&w)[R], int z) {
+    z = z < zmin ? zmin : z > zmax ? zmax : z;   // past the allocation: any plane, the data are not used
+    const char *pb = reinterpret_cast<const char *>(src + pzl * (z + 1));
+#pragma unroll
+    for (int j = 0; j < R; ++j) w[j] = *reinterpret_cast<const V2 *>(pb + gob[j]);
+  };
+
+  V2 P[NP][R];                                   // P[i] = plane k + 1 - i
+  V2 F[DF][R];                                   // planes in flight
+  T below[R];                                    // plane k - L - 1: the cell under the one the last stage updates
+#pragma unroll
+  for (int i = 0; i < NP; ++i)
+#pragma unroll
+    for (int j = 0; j < R; ++j) P[i][j].x = P[i][j].y = (T)0;
+#pragma unroll
+  for (int j = 0; j < R; ++j) below[j] = (T)0;
+  fetch(P[2], k0 - 1);
+  fetch(P[1], k0);
+  fetch(P[0], k0 + 1);
+  if (DF == 2) fetch(F[1], k0 + 2);
+
+#define MGX_TBQ(u, j) (((P0) + (u) + (HALO ? (j) : 0)) & 1)   /* position updated by every stage at unroll position u */
+#define MGX_CMP(v, q) ((q) ? (v).y : (v).x)
+  // raw red cells of plane k0 for stage 0 of the first step (red sits where black does not)
+#pragma unroll
+  for (int j = 0; j < R; ++j) A(0, 0, li[j]) = MGX_CMP(P[1][j], 1 - MGX_TBQ(0, j));
+
+  unsigned zs[L + 3];                            // Z sets of planes k+1 .. k-L-1 (global)
+#pragma unroll
+  for (int i = 0; i < L + 3; ++i) zs[i] = zset(k0 + 1 - i + g.z0);
+  unsigned xyany = 0u;
+  unsigned cc[L + 1][R];                         // codes of plane k - i: cell 0 | cell 1 << 16
+  int nvalid = 0;                                // planes k, k-1, ... whose codes are up to date
+#pragma unroll
+  for (int i = 0; i <= L; ++i)
+#pragma unroll
+    for (int j = 0; j < R; ++j) cc[i][j] = 0u;
+  __syncthreads();
+  if (BOXES) {
+    const uint4 xs4 = bl->xq[pcs];
+#pragma unroll
+    for (int j = 0; j < R; ++j) {
+      const uint4 ys4 = bl->yq[rr[j]];
+      xyany |= (xs4.x | xs4.y | xs4.z | xs4.w) & (ys4.x | ys4.y | ys4.z);
+    }
+  }
+  auto plane_codes = [&](unsigned (&out)[R], const unsigned zl, const unsigned zc, const unsigned zh) {
+    const uint4 xs4 = bl->xq[pcs];
+#pragma unroll
+    for (int j = 0; j < R; ++j) {
+      const uint4 ys = bl->yq[rr[j]];
+      out[j] = mgx_cell_code(xs4.y, xs4.x, xs4.z, ys, zl, zc, zh, cmask, rmask, tb0, tb1) |
+               (mgx_cell_code(xs4.z, xs4.y, xs4.w, ys, zl, zc, zh, cmask, rmask, tb0, tb1) << 16);
+    }
+  };
+
+  T err = (T)0;
+  u64 slo = 0, shi = 0;
+  double fh = 0.0, fl2 = 0.0;
+  unsigned ovf = 0;
+  bool rowin[R];
+#pragma unroll
+  for (int j = 0; j < R; ++j) {
+    const int r_ = __builtin_amdgcn_readfirstlane(wave) + NW * j;
+    rowin[j] = !HALO && r_ >= 2 * NS && r_ <= LR - 1 - 2 * NS;
+  }
+
+  // one step: U = unroll position (parity of k - k0)
+  auto step = [&](auto Uc, const int k) {
+    constexpr int U = decltype(Uc)::value;
+    fetch(F[DF == 2 ? U : 0], k + 1 + DF);
+    bool boxy = false;
+    if (BOXES) {
+      unsigned zor = 0u;
+#pragma unroll
+      for (int i = 0; i < L + 3; ++i) zor |= zs[i];
+      boxy = __any((xyany & zor) != 0u);
+      if (boxy) {
+        if (nvalid > L && NS > 1 && zs[0] == zs[2] && zs[1] == zs[3] && zs[2] == zs[4]) {
+#pragma unroll
+          for (int j = 0; j < R; ++j) cc[0][j] = cc[2][j];
+        } else {
+          plane_codes(cc[0], zs[2], zs[1], zs[0]);
+        }
+        if (__builtin_expect(nvalid <= L, 0)) {
+#pragma unroll
+          for (int i = 1; i <= L; ++i)
+            if (i > nvalid) plane_codes(cc[i], zs[i + 2], zs[i + 1], zs[i]);
+        }
+        nvalid = L + 1;
+      } else {
+        nvalid = 0;
+      }
+    }
+
+    auto stage = [&](auto Sc) {
+      constexpr int S = decltype(Sc)::value;
+      if constexpr (HALO && S == L) return;      // the last stage works on the tile proper: no halo pair
+      const int z = k - S, zg = z + g.z0;
+      if (zg >= 1 && zg <= g.n3g && z >= zc0 - (L - S) && z <= zc1 + (L - S)) {
+        T other[R], vym[R], vyp[R], vold[R], cnew[R];
+        bool actv[R];
+#pragma unroll
+        for (int j = 0; j < R; ++j) {
+          other[j] = A(S, U, li[j] + (2 * MGX_TBQ(U, j) - 1));
+          vym[j] = A(S, U, li[j] - LP);
+          vyp[j] = A(S, U, li[j] + LP);
+        }
+#pragma unroll
+        for (int j = 0; j < R; ++j) {
+          const int q = MGX_TBQ(U, j);
+          actv[j] = (fl[j] & (1u << (2 * S + q))) != 0u;
+          const T vc = MGX_CMP(P[S + 1][j], q), partner = MGX_CMP(P[S + 1][j], 1 - q);
+          const T zhi = MGX_CMP(P[S][j], q);
+          T zlo;
+          if constexpr (S == L) zlo = below[j]; else zlo = MGX_CMP(P[S + 2][j], q);
+          T vv;
+          if (BOXES != 0 && boxy) {
+            vv = mgx_cell_from_code<T, BOXES>((cc[S][j] >> (16 * q)) & 0xffffu, vc, q ? partner : other[j],
+                                              q ? other[j] : partner, vym[j], vyp[j], zlo, zhi, bl, pcs, rr[j], q,
+                                              zs[S + 2], zs[S + 1], zs[S], p);
+          } else {
+            // x-1 and x+1 carry the same weight and a*w + b*w commutes exactly: no need to order them
+            vv = p.s1 * vc + p.s2 * mgx_avg_uniform<T>(partner, other[j], vym[j], vyp[j], zlo, zhi, p.w);
+          }
+          vold[j] = vc;
+          cnew[j] = actv[j] ? vv : vc;
+          if (q) P[S + 1][j].y = cnew[j]; else P[S + 1][j].x = cnew[j];
+        }
+        if constexpr (S < L) {
+#pragma unroll
+          for (int j = 0; j < R; ++j) A(S + 1, 1 - U, li[j]) = cnew[j];
+        } else {
+          char *pb = reinterpret_cast<char *>(dst + pzl * (z + 1));
+#pragma unroll
+          for (int j = 0; j < R; ++j)
+            if (st[j]) {
+              typedef T nv2 __attribute__((ext_vector_type(2)));
+              nv2 o_;
+              o_.x = P[L + 1][j].x;
+              o_.y = P[L + 1][j].y;
+              __builtin_nontemporal_store(o_, reinterpret_cast<nv2 *>(pb + gob[j]));
+            }
+        }
+        if constexpr (S >= L - 1) {              // the last sweep of the pass carries the reductions
+          if (!HALO && reduce) {
+            const bool zown = z >= zc0 && z <= zc1;
+            double a_[R];
+#pragma unroll
+            for (int j = 0; j < R; ++j) {
+              const int q = MGX_TBQ(U, j);
+              const bool urow = zown && rowin[j];
+              if (urow) err = mgx_max_abs(err, cnew[j] - vold[j]);   // 0 where nothing was updated
+              a_[j] = mgx_abs_if((double)cnew[j], urow && (fl[j] & (1u << (16 + q))) != 0u);
+            }
+            if (reduce & 2) mgx_sum_items<R>(a_, fh, fl2, slo, shi, ovf);
+          }
+        }
+      }
+    };
+    stage(std::integral_constant<int, 0>{});
+    stage(std::integral_constant<int, 1>{});
+    if constexpr (NS > 1) {
+      stage(std::integral_constant<int, 2>{});
+      stage(std::integral_constant<int, 3>{});
+    }
+    // raw red cells of plane k+1 for stage 0 of the next step; the cell under the last stage's next cell
+#pragma unroll
+    for (int j = 0; j < R; ++j) {
+      A(0, 1 - U, li[j]) = MGX_CMP(P[0][j], MGX_TBQ(U, j));
+      below[j] = MGX_CMP(P[L + 1][j], 1 - MGX_TBQ(U, j));
+    }
+    __syncthreads();
+    // the window moves down one plane
+#pragma unroll
+    for (int i = NP - 1; i >= 1; --i)
+#pragma unroll
+      for (int j = 0; j < R; ++j) P[i][j] = P[i - 1][j];
+#pragma unroll
+    for (int j = 0; j < R; ++j) P[0][j] = F[DF == 2 ? 1 - U : 0][j];
+    if (BOXES) {
+#pragma unroll
+      for (int i = L + 2; i >= 1; --i) zs[i] = zs[i - 1];
+      zs[0] = zset(k + 2 + g.z0);
+#pragma unroll
+      for (int i = L; i >= 1; --i)
+#pragma unroll
+        for (int j = 0; j < R; ++j) cc[i][j] = cc[i - 1][j];
+      nvalid = nvalid > 0 ? (nvalid > L ? L + 1 : nvalid + 1) : 0;
+    }
+  };
+
+#pragma clang loop unroll(disable)
+  for (int kb = k0; kb <= zc1 + L; kb += 2) {
+    step(std::integral_constant<int, 0>{}, kb);
+    if (kb + 1 <= zc1 + L) step(std::integral_constant<int, 1>{}, kb + 1);
+    if (!HALO && (reduce & 2)) mgx_fast_sum_flush(fh, fl2, slo, shi);
+  }
+#undef MGX_TBQ
+#undef MGX_CMP
+  if (reduce) mgx_block_commit<NW + 1>((double)(err * err), slo, shi, ovf, reduce, res);
+}
+
+template <typename T, int NS, int TY, int BOXES, int NW, int DF>
+__device__ __forceinline__ void mgx_tb_tile(const T *__restrict__ src, T *__restrict__ dst, const MgxGeom &g,
+                                            const MgxSweepParams<T> &p, const MgxBox *__restrict__ bx, const int nb,
+                                            const int ntx, const int tile, const int zc0, const int zc1, const int reduce,
+                                            u64 *__restrict__ res, T *__restrict__ lds, MgxBoxLds<T> *__restrict__ bl) {
+  const int tx = tile % ntx, ty = tile / ntx;
+  const int tx0 = 1 + tx * 128, ty0 = 1 + ty * TY;
+  const int wave = threadIdx.x >> 6;
+  const bool halo = wave == NW;
+  // position of the black cell (odd x + y + z; pairs start at odd x) of the wave's first item on the plane of the first step
+  const int p0 = (ty0 - 2 * NS + (halo ? 0 : wave) + (zc0 - (2 * NS - 1)) + g.z0) & 1;
+  if (halo) {
+    if (p0) mgx_tb_body<T, NS, TY, BOXES, NW, DF, 1, true>(src, dst, g, p, bx, nb, tx0, ty0, zc0, zc1, reduce, res, lds, bl);
+    else mgx_tb_body<T, NS, TY, BOXES, NW, DF, 0, true>(src, dst, g, p, bx, nb, tx0, ty0, zc0, zc1, reduce, res, lds, bl);
+  } else {
+    if (p0) mgx_tb_body<T, NS, TY, BOXES, NW, DF, 1, false>(src, dst, g, p, bx, nb, tx0, ty0, zc0, zc1, reduce, res, lds, bl);
+    else mgx_tb_body<T, NS, TY, BOXES, NW, DF, 0, false>(src, dst, g, p, bx, nb, tx0, ty0, zc0, zc1, reduce, res, lds, bl);
+  }
+}
+
+template <typename T, int NS, int TY, int NW>
+constexpr size_t mgx_tb_lds_field() { return (size_t)(2 * NS) * 2 * (64 + 2 * NS) * (TY + 4 * NS + 2) * sizeof(T); }
+
+// `tiles` as for k_fused_sweep: three ints per block (tile column, first and last plane of the z chunk; -1 = padding),
+// in three segments: pieces some box with rho != 1 reaches, pieces only rho = 1 boxes reach, box-free pieces
+template <typename T, int NS, int TY, int NW, int DF>
+__global__ __launch_bounds__((NW + 1) * 64) void k_tb_sweep(const T *__restrict__ src, T *__restrict__ dst, const MgxGeom g,
+                                                            const MgxSweepParams<T> p, const MgxBox *__restrict__ bx,
+                                                            const int nb, const int ntx, const int *__restrict__ tiles,
+                                                            const int n_box, const int n_const, const int reduce,
+                                                            u64 *__restrict__ res) {
+  extern __shared__ __align__(16) unsigned char mgx_lds_raw[];
+  T *lds = reinterpret_cast<T *>(mgx_lds_raw);
+  MgxBoxLds<T> *bl = reinterpret_cast<MgxBoxLds<T> *>(mgx_lds_raw + mgx_tb_lds_field<T, NS, TY, NW>());
+  const int b = blockIdx.x;
+  const int cls = b < n_box ? 2 : b < n_box + n_const ? 1 : 0;
+  const int tile = tiles[3 * b], zc0 = tiles[3 * b + 1], zc1 = tiles[3 * b + 2];
+  if (tile < 0) return;
+  if (cls == 2) mgx_tb_tile<T, NS, TY, 2, NW, DF>(src, dst, g, p, bx, nb, ntx, tile, zc0, zc1, reduce, res, lds, bl);
+  else if (cls == 1) mgx_tb_tile<T, NS, TY, 1, NW, DF>(src, dst, g, p, bx, nb, ntx, tile, zc0, zc1, reduce, res, lds, bl);
+  else mgx_tb_tile<T, NS, TY, 0, NW, DF>(src, dst, g, p, bx, nb, ntx, tile, zc0, zc1, reduce, res, lds, bl);
+}
+
+template <typename T, int NS, int TY, int NW, int DF>
+static int mgx_tb_launch_cfg(const MgxFusedPlan &pl, const T *src, T *dst, const MgxGeom &g, const MgxSweepParams<T> &p,
+                             const MgxBox *bx, int nb, int reduce, u64 *res, hipStream_t st) {
+  constexpr size_t lds = mgx_tb_lds_field<T, NS, TY, NW>() + sizeof(MgxBoxLds<T>);
+  static bool attr_done[16] = {false};          // the attribute is per device and function: set once per device
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return -1;
+  if (lds > 64 * 1024 && !(dev >= 0 && dev < 16 && attr_done[dev])) {
+    if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_tb_sweep<T, NS, TY, NW, DF>),
+                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
+      return -1;
+    if (dev >= 0 && dev < 16) attr_done[dev] = true;
+  }
+  const MgxTileList &tl = pl.list[0];
+  const int total = tl.n_box + tl.n_const + tl.n_fast;
+  if (total > 0)
+    hipLaunchKernelGGL((k_tb_sweep<T, NS, TY, NW, DF>), dim3((unsigned)total), dim3((NW + 1) * 64), lds, st, src, dst, g, p, bx,
+                       nb, pl.ntx, pl.d_tiles + 3 * tl.offset, tl.n_box, tl.n_const, reduce, res);
+  return 0;
+}

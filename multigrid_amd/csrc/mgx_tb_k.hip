@@ -1,0 +1,22 @@
+// The two-sweeps-per-pass kernel (k_tb_sweep) and its launchers, a translation unit of its own.
+#include "mgx_tb.hpp"
+
+#include <cstdlib>
+
+// planes the kernel keeps in flight (1 or 2); MGX_TB_DF in the environment overrides, for benchmarking
+static int tb_df() {
+  static int df = 0;
+  if (!df) { const char *e = getenv("MGX_TB_DF"); df = (e && atoi(e) == 1) ? 1 : 2; }
+  return df;
+}
+
+int mgx_tb2_launch_f64(const MgxFusedPlan &pl, const double *src, double *dst, const MgxGeom &g,
+                       const MgxSweepParams<double> &p, const MgxBox *bx, int nb, int reduce, u64 *res, hipStream_t st) {
+  if (tb_df() == 1) return mgx_tb_launch_cfg<double, 2, 22, 6, 1>(pl, src, dst, g, p, bx, nb, reduce, res, st);
+  return mgx_tb_launch_cfg<double, 2, 22, 6, 2>(pl, src, dst, g, p, bx, nb, reduce, res, st);
+}
+int mgx_tb2_launch_f32(const MgxFusedPlan &pl, const float *src, float *dst, const MgxGeom &g,
+                       const MgxSweepParams<float> &p, const MgxBox *bx, int nb, int reduce, u64 *res, hipStream_t st) {
+  if (tb_df() == 1) return mgx_tb_launch_cfg<float, 2, 22, 6, 1>(pl, src, dst, g, p, bx, nb, reduce, res, st);
+  return mgx_tb_launch_cfg<float, 2, 22, 6, 2>(pl, src, dst, g, p, bx, nb, reduce, res, st);
+}

@@ -20,8 +20,9 @@ import csv, glob, collections
 tot = collections.defaultdict(lambda: [0.0, 0])
 for f in glob.glob("$OUT/p*/**/*counter_collection.csv", recursive=True):
     for row in csv.DictReader(open(f)):
-        if "k_fused_sweep" not in row["Kernel_Name"]: continue
-        key = (row["Kernel_Name"].split("k_fused_sweep")[1][:18], row["Counter_Name"])
+        kn = row["Kernel_Name"]
+        if "k_fused_sweep" not in kn and "k_tb_sweep" not in kn: continue
+        key = (kn[kn.index("k_"):][:34], row["Counter_Name"])
         tot[key][0] += float(row["Counter_Value"]); tot[key][1] += 1
 for k in sorted(tot): print(k, "avg per launch %.4g over %d launches" % (tot[k][0] / tot[k][1], tot[k][1]))
 PY
