@@ -155,6 +155,9 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if args.own_stream and args.gpus > 1:
+        raise SystemExit("--own-stream cannot be combined with --gpus > 1: RCCL transfers are ordered on torch's current "
+                         "stream, which the library must share")
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}")
     local_rank %= max(1, torch.cuda.device_count())      # rehearsals may put several ranks on one GPU

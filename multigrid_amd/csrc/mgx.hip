@@ -90,6 +90,8 @@ struct mgx_level {
 // two geometries only, so they are built on first use and kept until the level is destroyed
 struct MgxTransferPlan {
   int n_src[3] = {0, 0, 0};     // global size of the source level
+  int src_z0 = 0, src_n3 = 0;   // slab placement of the source the plan was checked and made for
+  int dst_z0 = 0, dst_n3 = 0;   // (the destination's cannot change, kept for symmetry)
   int method = 0;
   bool restrict_ = false;
   int *d_tab = nullptr;         // restriction: mx | my | mz (forward maps); prolongation: rx | ry | rz as (lo, hi) pairs
@@ -224,9 +226,14 @@ extern "C" int mgx_level_create_slab(mgx_ctx *ctx, int layer, const int32_t n[3]
   }
   hipError_t e = hipMalloc((void **)&lv->d_res, MGX_RES_WORDS * (1 + MGX_RES_SLOTS) * sizeof(u64));
   if (e != hipSuccess) { (void)hipFree(lv->buf[0]); (void)hipFree(lv->buf[1]); delete lv; return fail(MGX_ENOMEM, "hipMalloc(result)"); }
-  HIP_TRY(hipMemsetAsync(lv->buf[0], 0, bytes, ctx->stream));
-  HIP_TRY(hipMemsetAsync(lv->buf[1], 0, bytes, ctx->stream));
-  HIP_TRY(hipMemsetAsync(lv->d_res, 0, MGX_RES_WORDS * (1 + MGX_RES_SLOTS) * sizeof(u64), ctx->stream));
+  if (hipMemsetAsync(lv->buf[0], 0, bytes, ctx->stream) != hipSuccess ||
+      hipMemsetAsync(lv->buf[1], 0, bytes, ctx->stream) != hipSuccess ||
+      hipMemsetAsync(lv->d_res, 0, MGX_RES_WORDS * (1 + MGX_RES_SLOTS) * sizeof(u64), ctx->stream) != hipSuccess) {
+    (void)hipStreamSynchronize(ctx->stream);
+    (void)hipFree(lv->buf[0]); (void)hipFree(lv->buf[1]); (void)hipFree(lv->d_res);
+    delete lv;
+    return fail(MGX_EHIP, "mgx_level_create: zero fill failed");
+  }
   lv->shell_synced = true;
   lv->defined = true;
   *out = lv;
@@ -293,22 +300,26 @@ extern "C" int mgx_level_set_boxes(mgx_level *lv, int32_t nbox, const int32_t *p
   if (nbox < 0 || (nbox > 0 && (!place || !val || !rho || !constant)))
     return fail(MGX_EINVAL, "mgx_level_set_boxes: nbox = %d with NULL table", nbox);
   TRY(set_device(C(lv)));
-  lv->boxes.resize(nbox);
+  std::vector<MgxBox> table(nbox);          // the level keeps its old table unless the whole new one is valid
   for (int i = 0; i < nbox; ++i) {
-    MgxBox &b = lv->boxes[i];
+    MgxBox &b = table[i];
     for (int d = 0; d < 3; ++d) { b.lo[d] = place[6 * i + 2 * d]; b.hi[d] = place[6 * i + 2 * d + 1]; }
     b.constant = constant[i] != 0;
-    if (rho[i] < 0.0) return fail(MGX_EINVAL, "mgx_level_set_boxes: box %d has rho < 0 (t_mg.f90:352)", i);
+    if (!(rho[i] >= 0.0)) return fail(MGX_EINVAL, "mgx_level_set_boxes: box %d has rho < 0 (t_mg.f90:352)", i);
     b.val = lv->elem == 4 ? (double)(float)val[i] : val[i];   // box%val is real(grid_p)
     b.rho = lv->elem == 4 ? (double)(float)rho[i] : rho[i];
     b.rho_is_one = b.rho == 1.0;
   }
   HIP_TRY(hipStreamSynchronize(C(lv)->stream));   // kernels in flight may still read the old table
-  if (lv->d_boxes) { HIP_TRY(hipFree(lv->d_boxes)); lv->d_boxes = nullptr; }
+  MgxBox *d_new = nullptr;
   if (nbox > 0) {
-    HIP_TRY(hipMalloc((void **)&lv->d_boxes, sizeof(MgxBox) * nbox));
-    HIP_TRY(hipMemcpy(lv->d_boxes, lv->boxes.data(), sizeof(MgxBox) * nbox, hipMemcpyHostToDevice));
+    HIP_TRY(hipMalloc((void **)&d_new, sizeof(MgxBox) * nbox));
+    hipError_t e = hipMemcpy(d_new, table.data(), sizeof(MgxBox) * nbox, hipMemcpyHostToDevice);
+    if (e != hipSuccess) { (void)hipFree(d_new); return fail(MGX_EHIP, "mgx_level_set_boxes: upload: %s", hipGetErrorString(e)); }
   }
+  if (lv->d_boxes) (void)hipFree(lv->d_boxes);
+  lv->d_boxes = d_new;
+  lv->boxes.swap(table);
   lv->nbox = nbox;
   lv->count_cache = -1;
   lv->plan.valid = false;
@@ -420,15 +431,17 @@ static int sync_shell(mgx_level *lv) {
   return MGX_OK;
 }
 
-// Two sweeps per pass pay on levels whose z chunks are long against the six extra steps and eight extra planes of a
-// chunk and whose tile rows are wide enough to fill the 128 x 22 tiles: undivided levels from 96 x 44 x 64 cells on.
+// Two sweeps per pass pay where chunks of 64 planes (six extra steps and eight extra planes per chunk) of 128 x 22
+// tiles still fill the compute units twice over: undivided levels of about 400^3 cells and more (measured: 512^3
+// 0.67 ms per pair against 0.86 ms for two passes; 256^3 slower than two passes).
 template <typename T>
 static bool pair_pass_wanted(const mgx_level *lv) {
   const MgxGeom &g = lv->g;
   const int k = lv->ctx->kernel;
   if (mgx_pair_pass == 0 || k == MGX_KERNEL_FUSED || g.n3 != g.n3g || !mgx_fused_supported<T>(g, lv->nbox)) return false;
   if (mgx_pair_pass == 1 || k == MGX_KERNEL_PAIR) return true;
-  return g.n1 >= 96 && g.n2 >= 44 && g.n3 >= 64;
+  const long long pieces = (long long)((g.n1 + 127) / 128) * ((g.n2 + 21) / 22) * (g.n3 / 64);
+  return pieces >= 512;
 }
 
 template <typename T>
@@ -480,6 +493,7 @@ extern "C" int mgx_level_sweep(mgx_level *lv, int nsweeps, int reduce) {
   if (nsweeps < 0) return fail(MGX_EINVAL, "mgx_level_sweep: nsweeps = %d", nsweeps);
   if (!lv->params_set) return fail(MGX_ESTATE, "mgx_level_sweep: mgx_level_set_params not called");
   if (!lv->defined) return fail(MGX_ESTATE, "mgx_level_sweep: level %d was released", lv->layer);
+  if (lv->inner_pending) return fail(MGX_ESTATE, "mgx_level_sweep: the inner part of a split sweep is still due on level %d", lv->layer);
   if (lv->g.n3 != lv->g.n3g) {
     // a slab: the fused kernel reads halo planes -1, 0, n3+1, n3+2 as the caller left them; the in-place
     // kernel would need the neighbour's black planes between the two colours
@@ -727,7 +741,7 @@ static int transfer_plan(const char *who, bool restrict_, mgx_level *src, mgx_le
   const MgxGeom &gs = src->g, &gd = dst->g;
   for (MgxTransferPlan *t : dst->transfers)
     if (t->restrict_ == restrict_ && t->method == method && t->n_src[0] == gs.n1 && t->n_src[1] == gs.n2 &&
-        t->n_src[2] == gs.n3g) {
+        t->n_src[2] == gs.n3g && t->src_z0 == gs.z0 && t->src_n3 == gs.n3 && t->dst_z0 == gd.z0 && t->dst_n3 == gd.n3) {
       *out = t;
       return MGX_OK;
     }
@@ -750,6 +764,7 @@ static int transfer_plan(const char *who, bool restrict_, mgx_level *src, mgx_le
   TRY(check_z_reach(who, mz, src, dst));
   MgxTransferPlan *t = new MgxTransferPlan();
   t->n_src[0] = gs.n1; t->n_src[1] = gs.n2; t->n_src[2] = gs.n3g;
+  t->src_z0 = gs.z0; t->src_n3 = gs.n3; t->dst_z0 = gd.z0; t->dst_n3 = gd.n3;
   t->method = method;
   t->restrict_ = restrict_;
   std::vector<int> tab;
@@ -827,6 +842,7 @@ static int launch_prolong(bool half, mgx_level *src, mgx_level *dst, const MgxTr
 extern "C" int mgx_restrict(mgx_level *parent, mgx_level *child, int method) {
   TRY(check_pair("mgx_restrict", parent, child, method));
   if (!parent->defined) return fail(MGX_ESTATE, "mgx_restrict: parent level %d was released", parent->layer);
+  if (parent->inner_pending || child->inner_pending) return fail(MGX_ESTATE, "mgx_restrict: the inner part of a split sweep is still due");
   TRY(set_device(C(child)));
   MgxTransferPlan *t = nullptr;
   TRY(transfer_plan("mgx_restrict", true, parent, child, method, &t));
@@ -842,6 +858,7 @@ extern "C" int mgx_restrict(mgx_level *parent, mgx_level *child, int method) {
 extern "C" int mgx_prolong(mgx_level *child, mgx_level *parent, int method) {
   TRY(check_pair("mgx_prolong", child, parent, method));
   if (!child->defined) return fail(MGX_ESTATE, "mgx_prolong: child level %d was released", child->layer);
+  if (parent->inner_pending || child->inner_pending) return fail(MGX_ESTATE, "mgx_prolong: the inner part of a split sweep is still due");
   TRY(set_device(C(parent)));
   MgxTransferPlan *t = nullptr;
   TRY(transfer_plan("mgx_prolong", false, child, parent, method, &t));
@@ -886,6 +903,7 @@ extern "C" int mgx_level_upload(mgx_level *lv, const void *host) {
 extern "C" int mgx_level_download(mgx_level *lv, void *host) {
   if (!lv || !host) return fail(MGX_EINVAL, "mgx_level_download: NULL argument");
   if (!lv->defined) return fail(MGX_ESTATE, "mgx_level_download: level %d was released", lv->layer);
+  if (lv->inner_pending) return fail(MGX_ESTATE, "mgx_level_download: the inner part of a split sweep is still due on level %d", lv->layer);
   TRY(set_device(C(lv)));
   return copy_field(lv, host, false);
 }

@@ -31,6 +31,12 @@
 
 #include "mgx_fused.hpp"
 
+// The step barrier orders LDS traffic only: wait for this wave's LDS operations, not for its global loads and
+// stores (which __syncthreads() would drain: the planes in flight and the plane just stored).
+#ifndef MGX_TB_SYNC
+#define MGX_TB_SYNC() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+#endif
+
 template <int R>
 __device__ __forceinline__ void mgx_sum_items(const double (&a)[R], double &fh, double &fl2, u64 &slo, u64 &shi,
                                               unsigned &ovf) {
@@ -299,10 +305,7 @@ __device__ __forceinline__ void mgx_tb_body(const T *__restrict__ src, T *__rest
           cnew[j] = actv[j] ? vv : vc;
           if (q) P[S + 1][j].y = cnew[j]; else P[S + 1][j].x = cnew[j];
         }
-        if constexpr (S < L) {
-#pragma unroll
-          for (int j = 0; j < R; ++j) A(S + 1, 1 - U, li[j]) = cnew[j];
-        } else {
+        if constexpr (S == L) {
           char *pb = reinterpret_cast<char *>(dst + pzl * (z + 1));
 #pragma unroll
           for (int j = 0; j < R; ++j)
@@ -336,13 +339,19 @@ __device__ __forceinline__ void mgx_tb_body(const T *__restrict__ src, T *__rest
       stage(std::integral_constant<int, 2>{});
       stage(std::integral_constant<int, 3>{});
     }
-    // raw red cells of plane k+1 for stage 0 of the next step; the cell under the last stage's next cell
+    // What the next step's stages read in LDS, written after all reads of this step (a stage's result stays in the
+    // register window, so no stage's reads wait behind another stage's writes): stage s + 1 gets the cells stage s
+    // updated on plane k - s, stage 0 the raw red cells of plane k + 1.  (A stage that skipped its plane passes on
+    // cells nobody reads.)  Then the cell under the last stage's next cell.
 #pragma unroll
     for (int j = 0; j < R; ++j) {
-      A(0, 1 - U, li[j]) = MGX_CMP(P[0][j], MGX_TBQ(U, j));
-      below[j] = MGX_CMP(P[L + 1][j], 1 - MGX_TBQ(U, j));
+      const int q = MGX_TBQ(U, j);
+      A(0, 1 - U, li[j]) = MGX_CMP(P[0][j], q);
+#pragma unroll
+      for (int sgl = 0; sgl < L; ++sgl) A(sgl + 1, 1 - U, li[j]) = MGX_CMP(P[sgl + 1][j], q);
+      below[j] = MGX_CMP(P[L + 1][j], 1 - q);
     }
-    __syncthreads();
+    MGX_TB_SYNC();
     // the window moves down one plane
 #pragma unroll
     for (int i = NP - 1; i >= 1; --i)

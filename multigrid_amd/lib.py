@@ -106,6 +106,7 @@ class Context:
         _ck(self.L.mgx_ctx_create(device, C.c_void_p(stream) if stream else None, C.byref(h)))
         self.h = h
         self.device = device
+        self.stream = int(stream) if stream else None   # None: the library enqueues on a stream of its own
         self._levels = []
 
     def set_kernel(self, which: int):

@@ -63,6 +63,20 @@ def device_plane_tensor(lv: "lib.DeviceLevel", z: int, count: int):
     return t
 
 
+def check_stream_is_current(ctx):
+    """RCCL enqueues its transfers on torch's current stream.  They are ordered against the library's kernels (planes
+    written before they are sent, received before the next sweep reads them) only if the library enqueues on that
+    very stream; a context with a stream of its own would race them."""
+    import torch
+    cur = torch.cuda.current_stream(torch.device("cuda", ctx.device)).cuda_stream
+    mine = getattr(ctx, "stream", None)
+    if not mine or int(mine) != int(cur):
+        raise RuntimeError(
+            "z slabs over RCCL need the mgx context on torch's current stream: create a torch.cuda.Stream, make it "
+            "current (torch.cuda.set_stream) and pass its cuda_stream to multigrid_amd.lib.Context "
+            f"(context stream {mine!r}, current stream {cur!r}; the default stream, handle 0, cannot be passed)")
+
+
 class _StagedTransfers:
     """transfers of host copies of device planes (gloo): wait() also moves what was received onto the device"""
 
@@ -115,6 +129,8 @@ class SlabLevel:
         if ans is None:
             ctx = getattr(self.lv, "ctx", None)
             ans = ctx is None or self.world == 1 or self.dist.get_backend(self.group) != "gloo"
+            if ans and ctx is not None and self.world > 1:
+                check_stream_is_current(ctx)
             self._ordered = ans
         return ans
 

@@ -19,7 +19,7 @@ import numpy as np
 _HERE = os.path.dirname(os.path.abspath(__file__))
 _LIB_PATH = os.path.join(_HERE, "_build", "libmg_oracle.so")
 
-ORDER_LEX, ORDER_RB = 0, 1
+ORDER_LEX, ORDER_RB, ORDER_RB_RED_FIRST = 0, 1, 2
 SUM_SEQ, SUM_EXACT = 0, 1
 METHOD_BOTTOM_UP, METHOD_W = 1, 2
 BC_PERIODIC, BC_DIRICHLET, BC_NEUMANN = 1, 2, 3
@@ -224,6 +224,10 @@ def prolong(Cl: Level, Vc: np.ndarray, P: Level, Vp: np.ndarray) -> None:
     getattr(lib(), f"orc_prolong_{_sfx(Vp.dtype)}")(C.byref(arr[0]), _ptr(Vc), C.byref(arr[1]), _ptr(Vp))
 
 
+class SolveStopped(RuntimeError):
+    """orc_solve ran into max_sweeps; .hist holds the history up to there, .sweeps the sweeps per level"""
+
+
 def solve(levels: Sequence[Level], method: int, dtype, order: int = ORDER_RB, sum_mode: int = SUM_EXACT,
           hist_cap: int = 1 << 20, max_sweeps: int = 1 << 24):
     """mg_gs_cds restated; returns (Vtop, history structured array, sweeps per level)"""
@@ -235,6 +239,11 @@ def solve(levels: Sequence[Level], method: int, dtype, order: int = ORDER_RB, su
     n = getattr(lib(), f"orc_solve_{_sfx(dtype)}")(
         arr, len(levels), method, order, sum_mode, _ptr(V),
         hist.ctypes.data_as(C.POINTER(_Hist)), hist_cap, per, max_sweeps)
+    if n == -2:
+        e = SolveStopped(f"orc_solve stopped after max_sweeps = {max_sweeps} sweeps without meeting its tolerance")
+        e.hist = hist[hist["layer"] > 0].copy()       # the records written before the stop
+        e.sweeps = [int(x) for x in per]
+        raise e
     if n < 0:
         raise RuntimeError(f"orc_solve failed with {n}")
     if n > hist_cap:
