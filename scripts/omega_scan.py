@@ -27,7 +27,7 @@ boxes 4
 method v-cycle
 begin layers
   sor {sor}
-  tol 1.e-6
+  tol 1.e-5
   v-steps 2
   mesh-size {n} {n} {n}
   bc a periodic
@@ -74,12 +74,15 @@ def run(job):
     top = mgio.iomg_read(IO, dtype=np.float64)
     try:
         V, hist, per = orc.solve(oracle_levels(top), mgio.read_method(IO), np.float64, order=order,
-                                 sum_mode=orc.SUM_SEQ, max_sweeps=2500)
+                                 sum_mode=orc.SUM_SEQ, max_sweeps=4000)
     except orc.SolveStopped as e:
+        # maximum principle: |V| never exceeds the largest box value (0.5 here), so sum|V| <= 0.5 N for any state of a
+        # converging iteration; beyond N cells the iteration has left that range for good
         sums = e.hist["sum"]
-        if len(sums) and (not np.isfinite(sums[-1]) or abs(sums[-1]) > 50 * max(abs(sums[0]), 1e-30)):
-            return case, sor, oname, f"DIVERGES (sum|V| {sums[0]:.3g} -> {sums[-1]:.3g} after {sum(e.sweeps)} sweeps)"
-        return case, sor, oname, f"not converged in {sum(e.sweeps)} sweeps (sum|V| {sums[0]:.3g} -> {sums[-1]:.3g})"
+        ncell = float(np.prod([int(v) for v in top.n]))
+        if len(sums) and (not np.isfinite(sums[-1]) or abs(sums[-1]) > ncell):
+            return case, sor, oname, f"DIVERGES (sum|V| {sums[-1]:.2g} > N = {ncell:.2g} after {sum(e.sweeps)} sweeps)"
+        return case, sor, oname, f"no divergence, tolerance not met in {sum(e.sweeps)} sweeps"
     vmax = float(np.nanmax(np.abs(V))) if np.isfinite(V).any() else float("inf")
     if not np.isfinite(V).all() or vmax > 1e3:
         k = int(np.argmax(~np.isfinite(hist["sum"]) | (np.abs(hist["sum"]) > 1e3 * max(1.0, abs(hist["sum"][0])))))
