@@ -133,6 +133,15 @@ int mgx_level_result(mgx_level *lv, double *err_sq_max, double *abs_sum, uint64_
  * rounded once to double — the same bits for any tiling or GPU count. [sync] */
 int mgx_level_abs_sum(mgx_level *lv, double *sum);
 int mgx_level_abs_sum_limbs(mgx_level *lv, uint64_t limbs[2]);    /* [sync] low, high word */
+/* No counterpart in the reference: grid_sum for callers that cannot allocate device memory or wait for the device
+ * (code under HIP graph capture, tight serving loops, harnesses that forbid hipMalloc).  Same integer sum as
+ * mgx_level_abs_sum_limbs, but the partial sums live in a static device array of the library (512 KiB per GPU, held
+ * until the process ends), nothing is allocated and nothing waits: out_device (3 x uint64 in DEVICE memory, owned
+ * by the caller) receives low limb, high limb and the number of cells with |V| >= 2^20 or not finite (non-zero: the
+ * limbs are not the sum) on the context's stream.  Limit: n2 * n3_local <= 524288 rows (MGX_ELIMIT beyond; a
+ * 512^3 level has 262144, a 2048 x 2048 x 256 slab 524288).  Calls that overlap on one GPU (different streams)
+ * share the array and race; calls on one stream are ordered. */
+int mgx_level_abs_sum_noalloc(mgx_level *lv, uint64_t *out_device);
 /* helper: 128-bit integer (units of 2^-72) -> nearest-even double */
 double mgx_limbs_to_double(const uint64_t limbs[2]);
 

@@ -44,6 +44,17 @@ static int fail(int code, const char *fmt, ...) {
 extern "C" const char *mgx_last_error(void) { return g_err; }
 extern "C" const char *mgx_version(void) { return "mgx 0.1 (gfx950)"; }
 
+// ---- scratch of the entry point that allocates nothing (mgx_level_abs_sum_noalloc) ----
+// One record of MGX_NOALLOC_REC words per block of the partial-sum kernel.  Every GPU the library runs on holds
+// its own copy of the array until the process ends.  In host code the array's name is only a stand-in: the
+// device address is asked for once per device (mgx_ctx_create, that device current) and kept in g_scratch_ptr.
+#define MGX_NOALLOC_REC 8
+#define MGX_NOALLOC_MAX_BLOCKS 8192
+#define MGX_NOALLOC_ROWS_PER_BLOCK 64
+#define MGX_MAX_DEVICES 64
+static __device__ __align__(256) u64 scratch[MGX_NOALLOC_MAX_BLOCKS * MGX_NOALLOC_REC];   // 512 KiB
+static u64 *g_scratch_ptr[MGX_MAX_DEVICES] = {nullptr};
+
 static int mgx_pair_pass = -1;   // 0: never two sweeps per pass, 1: wherever the kernel applies, -1: where it pays (default)
 
 // ------------------------------------------------------------------------------------------------
@@ -158,6 +169,12 @@ extern "C" int mgx_ctx_create(int device, void *stream, mgx_ctx **out) {
       hipEventCreateWithFlags(&c->ev_join, hipEventDisableTiming) != hipSuccess) {
     delete c;
     return fail(MGX_EHIP, "mgx_ctx_create: side stream / events");
+  }
+  if (device < MGX_MAX_DEVICES && !g_scratch_ptr[device]) {      // this device is current (hipSetDevice above)
+    void *ptr = nullptr;
+    hipError_t es = hipGetSymbolAddress(&ptr, HIP_SYMBOL(scratch));
+    if (es != hipSuccess || !ptr) { (void)mgx_ctx_destroy(c); return fail(MGX_EHIP, "mgx_ctx_create: hipGetSymbolAddress(scratch): %s", hipGetErrorString(es)); }
+    g_scratch_ptr[device] = (u64 *)ptr;
   }
   *out = c;
   return MGX_OK;
@@ -619,6 +636,38 @@ extern "C" int mgx_level_abs_sum_limbs(mgx_level *lv, uint64_t limbs[2]) {
   double s;
   TRY(fetch_result(lv, nullptr, &s, limbs));
   if (std::isnan(s)) return fail(MGX_ELIMIT, "mgx_level_abs_sum: a value is >= 2^20 or not finite");
+  return MGX_OK;
+}
+
+// grid_sum without any allocation and without waiting: block b of k_abs_sum_parts sums MGX_NOALLOC_ROWS_PER_BLOCK
+// rows and writes its own record of the static scratch array (plain stores: nothing has to start at zero, whatever
+// an earlier call left is overwritten or not read), one block of k_fold_parts adds the records of this call and
+// writes (low limb, high limb, overflow count) to the caller's device words.
+extern "C" int mgx_level_abs_sum_noalloc(mgx_level *lv, uint64_t *out_device) {
+  if (!lv || !out_device) return fail(MGX_EINVAL, "mgx_level_abs_sum_noalloc: NULL argument");
+  if (!lv->defined) return fail(MGX_ESTATE, "mgx_level_abs_sum_noalloc: level %d was released", lv->layer);
+  if (lv->inner_pending) return fail(MGX_ESTATE, "mgx_level_abs_sum_noalloc: the inner part of a split sweep is still due");
+  const MgxGeom &g = lv->g;
+  const long long rows = (long long)g.n2 * g.n3;
+  const long long nblocks = (rows + MGX_NOALLOC_ROWS_PER_BLOCK - 1) / MGX_NOALLOC_ROWS_PER_BLOCK;
+  if (nblocks > MGX_NOALLOC_MAX_BLOCKS)
+    return fail(MGX_ELIMIT, "mgx_level_abs_sum_noalloc: n2 * n3 = %lld rows exceed the %d rows the static scratch array "
+                "holds partial sums for; use mgx_level_abs_sum_limbs", rows, MGX_NOALLOC_MAX_BLOCKS * MGX_NOALLOC_ROWS_PER_BLOCK);
+  mgx_ctx *c = C(lv);
+  TRY(set_device(c));
+  if (c->device >= MGX_MAX_DEVICES || !g_scratch_ptr[c->device])
+    return fail(MGX_ESTATE, "mgx_level_abs_sum_noalloc: no scratch address for device %d", c->device);
+  u64 *parts = g_scratch_ptr[c->device];       // the device address, never the array's name
+  TRY(materialize(lv));                         // a pending zero fill is a memset, not an allocation
+  if (lv->elem == 4)
+    hipLaunchKernelGGL((k_abs_sum_parts<float>), dim3((unsigned)nblocks), dim3(256), 0, c->stream, (const float *)lv->buf[lv->cur], g,
+                       MGX_NOALLOC_ROWS_PER_BLOCK, MGX_NOALLOC_REC, parts);
+  else
+    hipLaunchKernelGGL((k_abs_sum_parts<double>), dim3((unsigned)nblocks), dim3(256), 0, c->stream, (const double *)lv->buf[lv->cur], g,
+                       MGX_NOALLOC_ROWS_PER_BLOCK, MGX_NOALLOC_REC, parts);
+  HIP_TRY(hipGetLastError());
+  hipLaunchKernelGGL(k_fold_parts, dim3(1), dim3(256), 0, c->stream, (const u64 *)parts, (int)nblocks, MGX_NOALLOC_REC, (u64 *)out_device);
+  HIP_TRY(hipGetLastError());
   return MGX_OK;
 }
 

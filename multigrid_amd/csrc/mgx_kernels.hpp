@@ -238,6 +238,63 @@ __global__ __launch_bounds__(256) void k_abs_sum(const T *__restrict__ V, const 
   mgx_block_commit<4>(0.0, lo, hi, ovf, 2, res);
 }
 
+// grid_sum with one record per block and no atomics: block b sums rows [b*rpb, (b+1)*rpb) of the level's n2*n3 interior
+// rows (y fastest) and stores the four 32-bit digits of its exact sum and its overflow count to parts[b*rec ..]
+template <typename T>
+__global__ __launch_bounds__(256) void k_abs_sum_parts(const T *__restrict__ V, const MgxGeom g, const int rpb, const int rec,
+                                                       u64 *__restrict__ parts) {
+  __shared__ u64 sh[4][5];
+  u64 lo = 0, hi = 0;
+  unsigned ovf = 0;
+  const long long rows = (long long)g.n2 * g.n3;
+  const int w = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const long long r0 = (long long)blockIdx.x * rpb, r1 = r0 + rpb < rows ? r0 + rpb : rows;
+  for (long long r = r0 + w; r < r1; r += 4) {
+    const int y = (int)(r % g.n2) + 1;
+    const int z = (int)(r / g.n2) + 1;
+    const T *row = V + g.idx(1, y, z);
+    for (int x = lane; x < g.n1; x += 64) {
+      const T v = row[x];
+      mgx_exact_add(lo, hi, (double)(v < (T)0 ? -v : v), ovf);
+    }
+  }
+  const u64 d0 = mgx_wave_add(lo & 0xFFFFFFFFull), d1 = mgx_wave_add(lo >> 32), d2 = mgx_wave_add(hi & 0xFFFFFFFFull),
+            d3 = mgx_wave_add(hi >> 32), of = mgx_wave_add((u64)ovf);
+  if (lane == 0) { sh[w][0] = d0; sh[w][1] = d1; sh[w][2] = d2; sh[w][3] = d3; sh[w][4] = of; }
+  __syncthreads();
+  if (threadIdx.x < 5) parts[(size_t)blockIdx.x * rec + threadIdx.x] = sh[0][threadIdx.x] + sh[1][threadIdx.x] + sh[2][threadIdx.x] + sh[3][threadIdx.x];
+}
+
+#ifdef MGX_MAIN_UNIT
+// adds the first n records of `parts` (digits may exceed 32 bits: positional sum with carries) and writes
+// out[0] = low limb, out[1] = high limb of the 128-bit sum, out[2] = overflow count; one block of 256 threads
+__global__ __launch_bounds__(256) void k_fold_parts(const u64 *__restrict__ parts, const int n, const int rec, u64 *__restrict__ out) {
+  __shared__ u64 sh[4][5];
+  u64 d[5] = {0, 0, 0, 0, 0};
+  for (int b = threadIdx.x; b < n; b += 256)
+#pragma unroll
+    for (int k = 0; k < 5; ++k) d[k] += parts[(size_t)b * rec + k];
+#pragma unroll
+  for (int k = 0; k < 5; ++k) d[k] = mgx_wave_add(d[k]);
+  const int w = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0)
+    for (int k = 0; k < 5; ++k) sh[w][k] = d[k];
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    u64 t[5];
+    for (int k = 0; k < 5; ++k) t[k] = sh[0][k] + sh[1][k] + sh[2][k] + sh[3][k];
+    // value = t0 + t1 * 2^32 + t2 * 2^64 + t3 * 2^96 (mod 2^128)
+    u64 lo = t[0], hi = t[2] + (t[3] << 32);
+    const u64 a = t[1] << 32;
+    lo += a;
+    hi += (t[1] >> 32) + (lo < a ? 1ull : 0ull);
+    out[0] = lo;
+    out[1] = hi;
+    out[2] = t[4];
+  }
+}
+#endif
+
 // ------------------------------------------------------------------------------------------------
 // grid_setup pieces (t_mg.f90:465-588)
 

@@ -137,6 +137,12 @@ module mgx_c
        integer(c_int64_t), intent(out) :: limbs(2)         ! bit patterns of the two uint64_t words
        integer(c_int) :: rc
      end function mgx_level_abs_sum_limbs
+     function mgx_level_abs_sum_noalloc(lv, out_device) bind(C, name="mgx_level_abs_sum_noalloc") result(rc)
+       import :: c_int, c_ptr
+       type(c_ptr), value :: lv
+       type(c_ptr), value :: out_device                    ! 3 x uint64_t in DEVICE memory
+       integer(c_int) :: rc
+     end function mgx_level_abs_sum_noalloc
      function mgx_limbs_to_double(limbs) bind(C, name="mgx_limbs_to_double") result(v)
        import :: c_int64_t, c_double
        integer(c_int64_t), intent(in) :: limbs(2)

@@ -27,6 +27,7 @@ SYMBOLS = [
     "mgx_level_set_params", "mgx_level_set_boxes", "mgx_level_setup", "mgx_level_sweep", "mgx_level_sweep_part",
     "mgx_level_half_sweep",
     "mgx_level_result_reset", "mgx_level_result", "mgx_level_abs_sum", "mgx_level_abs_sum_limbs",
+    "mgx_level_abs_sum_noalloc",
     "mgx_limbs_to_double", "mgx_level_count_nonconst", "mgx_level_tolerance", "mgx_restrict", "mgx_prolong",
     "mgx_level_upload", "mgx_level_download", "mgx_level_plane_ptr", "mgx_level_halo_written", "mgx_level_info",
 ]
@@ -76,6 +77,7 @@ def load():
         "mgx_level_result_reset": [vp],
         "mgx_level_result": [vp, pdbl, pdbl, pu64],
         "mgx_level_abs_sum": [vp, pdbl], "mgx_level_abs_sum_limbs": [vp, pu64],
+        "mgx_level_abs_sum_noalloc": [vp, vp],
         "mgx_level_count_nonconst": [vp, C.POINTER(i64)],
         "mgx_level_tolerance": [vp, dbl, pdbl],
         "mgx_restrict": [vp, vp, C.c_int], "mgx_prolong": [vp, vp, C.c_int],
@@ -213,6 +215,10 @@ class DeviceLevel:
         limbs = (C.c_uint64 * 2)()
         _ck(self.L.mgx_level_abs_sum_limbs(self.h, limbs))
         return (int(limbs[1]) << 64) | int(limbs[0])
+
+    def abs_sum_noalloc(self, out_device_ptr: int):
+        """enqueue grid_sum without allocating or waiting; the three result words land at the DEVICE address given"""
+        _ck(self.L.mgx_level_abs_sum_noalloc(self.h, C.c_void_p(int(out_device_ptr))))
 
     def count_nonconst(self) -> int:
         n = C.c_int64()
