@@ -1,23 +1,23 @@
 #!/usr/bin/env python3
 """Benchmark of the V-cycle hot path on MI355X.
 
-One "step" = one full red-black SOR sweep (black + red half-sweeps, with the fused max-dV^2 and
-sum|V| reductions that the host convergence loop reads, m_gs_CDS.F90:200-210) of the finest level
-of the 512^3 mixed-boundary configuration, fp64, field resident in HBM.  `value` = lattice updates
-per second of the whole job (all ranks).  With --gpus N > 1 the level is z-slab decomposed, every
-rank owning a 512 x 512 x 512 slab of a 512 x 512 x (512 N) level (weak scaling): two halo planes
-per neighbour are exchanged per sweep over RCCL and the reductions are all-reduced; afterwards rank 0
-repeats the sweeps on the undivided level and reports whether the reductions agree bit for bit
-(`check.undivided.identical`).
+--gpus 1 (default): one "step" = one full red-black SOR sweep (black + red half-sweeps, with the fused max-dV^2
+and sum|V| reductions that the host convergence loop reads, m_gs_CDS.F90:200-210) of the finest level of the
+512^3 mixed-boundary configuration (config 3), fp64, field resident in HBM.  `value` = lattice updates per second.
+--gpus N > 1: the 2048^3 periodic configuration (config 5; --config 4 selects 256 x 256 x 4096) decomposed into N
+z slabs, strong scaling: every rank sweeps its slab, two halo planes per neighbour travel per sweep over RCCL
+beside the bulk of the sweep, the reductions are all-reduced.  `value` = lattice updates per second of the whole job.
 
 The JSON line also carries
-  roofline      achieved HBM GB/s of the sweep kernel (16 B per lattice update: one read + one write
-                of every cell per sweep) from HIP events on the kernel's stream, against 8 TB/s
-  cpu_baseline  the reference's own smoother (compiled from the reference sources into
-                oracle/_ref/, OpenMP) — or the C oracle if that binary is not present — timed on a
-                bounded sample on this host
-  vcycle        wall time of the complete `method v-cycle` solve of the same input to its
-                tolerance (tol 1e-8 unless --vcycle-tol), with sweep counts per level
+  roofline      achieved HBM GB/s of the sweep kernel (16 B per lattice update: one read + one write of every cell per
+                sweep) from HIP events on the kernel's stream, against 8 TB/s; sub-objects `on_solution` (the same
+                launch on the converged potential) and `pair_pass` (two sweeps in one pass over the field, the form
+                gs_V's legs run in: 16 B per cell per PASS)
+  cpu_baseline  the reference's own smoother (compiled from the reference sources into oracle/_ref/, OpenMP) — or the
+                C oracle if that binary is not present — timed on a bounded sample on this host, all cores and one
+  vcycle        wall time of the complete `method v-cycle` solve of config 3 to its tolerance (tol 1e-8 unless
+                --vcycle-tol), with sweep counts per level; with --gpus N > 1 the same solve with every level
+                decomposed into z slabs over the N GPUs
 """
 from __future__ import annotations
 
@@ -82,17 +82,101 @@ end box
 """
 
 
-def cpu_baseline(seconds_target: float = 15.0):
-    """The reference's gs_step on this host's cores, on a bounded sample (256^3 of the same geometry)."""
+def config5_input(n=(2048, 2048, 2048), tol="1.e-8", sor="1.7", steps=2) -> str:
+    """2048^3 fully periodic case (config 5; config 2 is the same at 256^3): two plate electrodes +-0.5"""
+    L = [0.1 * v for v in n]
+    def f(v):
+        return f"{v:.10g}"
+    return f"""
+cell {f(L[0])} {f(L[1])} {f(L[2])}
+max-layers 8
+boxes 4
+method v-cycle
+begin layers
+  sor {sor}
+  tol {tol}
+  v-steps {steps}
+  mesh-size {n[0]} {n[1]} {n[2]}
+  bc all periodic
+  interp full
+end layers
+begin box
+  llc {f(0.25 * L[0])} {f(0.25 * L[1])} 0.
+  cell {f(0.5 * L[0])} {f(0.5 * L[1])} {f(0.05 * L[2])}
+  value 0.5
+end box
+begin box
+  llc {f(0.25 * L[0])} {f(0.25 * L[1])} {f(0.95 * L[2])}
+  cell {f(0.5 * L[0])} {f(0.5 * L[1])} {f(0.05 * L[2])}
+  value -0.5
+end box
+"""
+
+
+def config4_input(n=(256, 256, 4096), tol="1.e-8", sor="1.7", steps=2) -> str:
+    """elongated electrode geometry (config 4): electrodes at the two z ends, `max-layers 4` keeps every level an exact
+    halving, a per-layer block tightens the coarsest level"""
+    L = [0.1 * v for v in n]
+    def f(v):
+        return f"{v:.10g}"
+    return f"""
+cell {f(L[0])} {f(L[1])} {f(L[2])}
+max-layers 4
+boxes 4
+method v-cycle
+begin layers
+  sor {sor}
+  tol {tol}
+  v-steps {steps}
+  mesh-size {n[0]} {n[1]} {n[2]}
+  bc all periodic
+  bc c- neumann
+  bc c+ dirichlet
+  interp full
+end layers
+begin layer -1
+  tol 1.e-9
+end layer
+begin box
+  llc {f(0.25 * L[0])} {f(0.25 * L[1])} 0.
+  cell {f(0.5 * L[0])} {f(0.5 * L[1])} {f(0.05 * L[2])}
+  value 0.5
+end box
+begin box
+  llc {f(0.25 * L[0])} {f(0.25 * L[1])} {f(0.95 * L[2])}
+  cell {f(0.5 * L[0])} {f(0.5 * L[1])} {f(0.05 * L[2])}
+  value -0.5
+end box
+"""
+
+
+def host_cores():
+    """the cores this process may use: its affinity mask, capped by the thread count the environment prescribes"""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    cap = os.environ.get("OMP_NUM_THREADS", "")
+    if cap.isdigit() and int(cap) > 0:
+        n = min(n, int(cap))
+    return max(1, n)
+
+
+def cpu_baseline(seconds_target: float = 12.0, n=(512, 512, 512)):
+    """The reference's gs_step on this host's cores, on a bounded sample of the bench geometry: every core this
+    process may use, and one thread (the only reproducible figure: the reference's OpenMP sweep is racy)."""
     from multigrid_amd import mgio
-    n = (256, 256, 256)
     top = mgio.iomg_read(mgio.MgIO(text=config3_input(n)))
-    cores = max(1, min(16, os.cpu_count() or 1))
-    exe = os.path.join(ROOT, "oracle", "_ref", "ref_driver_omp_f64")
+    cores = host_cores()
+    visible = os.cpu_count() or 1
+    exe = os.path.join(ROOT, "oracle", "_ref", "ref_driver_omp_O3_f64")
+    flags = "-O3 -fopenmp"
+    if not os.path.exists(exe):
+        exe, flags = os.path.join(ROOT, "oracle", "_ref", "ref_driver_omp_f64"), "-O2 -fopenmp"
     boxes = [b for b in top.box if not np.all(b.place == 0)]
     if os.path.exists(exe):
         try:
-            def run(k):
+            def run(k, threads):
                 with tempfile.TemporaryDirectory() as td:
                     case, out = os.path.join(td, "case.txt"), os.path.join(td, "out.bin")
                     with open(case, "w") as fcase:
@@ -100,20 +184,27 @@ def cpu_baseline(seconds_target: float = 15.0):
                         for b in boxes:
                             fcase.write(" ".join(str(int(v)) for v in b.place) + f" {b.val!r} {b.rho!r} {int(b.constant)}\n")
                         fcase.write(f"{k}\n1 1 1\n0\n")
-                    env = dict(os.environ, OMP_NUM_THREADS=str(cores))
+                    env = dict(os.environ, OMP_NUM_THREADS=str(threads))
                     txt = subprocess.run([exe, case, out], env=env, check=True, stdout=subprocess.PIPE,
                                          universal_newlines=True, timeout=600).stdout
                     return float(txt.split("REF_SWEEP_SECONDS")[1].split()[0])
-            t2 = run(2)
+            cells = n[0] * n[1] * n[2]
+            t2 = run(2, cores)
             k = int(max(2, min(400, seconds_target / max(t2 / 2, 1e-6))))
-            t = run(k)
-            return dict(value=n[0] * n[1] * n[2] * k / t / 1e9, unit="GLUP/s", cores=cores, kind="reference",
-                        sample=f"{k} gs_step sweeps (reference's lexicographic OpenMP smoother, amdflang -O2 -fopenmp, "
-                               f"fp64 build) on {n[0]}x{n[1]}x{n[2]} of the bench geometry, {t:.1f} s")
+            t = run(k, cores)
+            k1 = int(max(1, min(k, seconds_target / max(t2 / 2 * cores * 0.5, 1e-6))))
+            t1 = run(k1, 1)
+            return dict(value=cells * k / t / 1e9, unit="GLUP/s", cores=cores, kind="reference",
+                        sample=f"{k} gs_step sweeps (reference's lexicographic OpenMP smoother, amdflang {flags}, fp64 build) "
+                               f"on {n[0]}x{n[1]}x{n[2]} of the bench geometry, {t:.1f} s on {cores} threads "
+                               f"(host shows {visible} CPUs); 1 thread: {k1} sweeps in {t1:.1f} s",
+                        one_thread_value=cells * k1 / t1 / 1e9, host_cpus_visible=visible)
         except Exception as e:   # binary not runnable here: fall through to the port
             sys.stderr.write(f"[bench] reference binary failed ({e}); timing the C oracle instead\n")
     from oracle import oracle as orc
     from tests.helpers import oracle_levels
+    n = (256, 256, 256)
+    top = mgio.iomg_read(mgio.MgIO(text=config3_input(n)))
     L = oracle_levels(top)[0]
     V = np.zeros(L.shape())
     orc.setup(L, V, True)
@@ -132,17 +223,19 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=50)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--size", dest="n", type=int, default=512, help="cells per dimension of one GPU's slab")
+    ap.add_argument("--size", dest="n", type=int, default=512, help="--gpus 1: cells per dimension of config 3")
+    ap.add_argument("--config", type=int, default=0, help="--gpus N > 1: 5 (2048^3 periodic, default) or 4 (256 x 256 x 4096)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-vcycle", action="store_true")
     ap.add_argument("--no-fortran-host", action="store_true", help="skip the v-cycle solve through the Fortran host")
     ap.add_argument("--vcycle-tol", default="1.e-8")
     ap.add_argument("--sor", default="1.7")
-    ap.add_argument("--kernel", type=int, default=0, help="0 auto, 1 two-pass, 2 fused")
+    ap.add_argument("--kernel", type=int, default=0, help="0 auto, 1 two-pass, 2 fused (one sweep per pass), 3 fused with pair passes everywhere")
     ap.add_argument("--own-stream", action="store_true", help="let the library create its stream (events then see nothing)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for --gpus > 1 (nccl = RCCL)")
-    ap.add_argument("--dist-vcycle", action="store_true",
-                    help="with --gpus > 1: also time the complete v-cycle solve with every level decomposed into z slabs")
+    ap.add_argument("--no-dist-vcycle", action="store_true",
+                    help="with --gpus > 1: skip the v-cycle solve of config 3 with every level decomposed into z slabs")
+    ap.add_argument("--dist-size", type=int, default=0, help="with --gpus > 1: cells per dimension instead of the configuration's (rehearsals)")
     ap.add_argument("--no-verify", action="store_true",
                     help="with --gpus > 1: skip the comparison of the reductions with the undivided level on rank 0")
     ap.add_argument("--no-overlap", action="store_true", help="exchange the halo planes after the whole sweep")
@@ -173,7 +266,6 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
-    n = args.n
     # a stream of torch's own (the default stream has handle 0): the library enqueues on it, so the
     # events below bracket exactly the kernels of the timed region
     tstream = torch.cuda.Stream()
@@ -181,27 +273,58 @@ def main():
     ctx = lib.Context(local_rank, None if args.own_stream else tstream.cuda_stream)
     ctx.set_kernel(args.kernel)
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    RED = lib.RED_ERR | lib.RED_SUM
+
+    def timed(fn, reps):
+        """device time per call of fn on the library's stream (HIP events) and host wall time per call"""
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        ev0.record()
+        for _ in range(reps):
+            fn()
+        ev1.record()
+        torch.cuda.synchronize()
+        return ev0.elapsed_time(ev1) / reps, (time.perf_counter() - t0) / reps * 1e3
 
     if world == 1:
-        top = mgio.iomg_read(mgio.MgIO(text=config3_input((n, n, n), tol=args.vcycle_tol, sor=args.sor)))
+        n = args.n
+        dims = (n, n, n)
+        top = mgio.iomg_read(mgio.MgIO(text=config3_input(dims, tol=args.vcycle_tol, sor=args.sor)))
         solver = cycle.Solver(top, ctx=ctx)
         solver.bring_back(top)
         solver.setup(top, True)
         lv = top.dev
 
         def step():
-            lv.sweep(1, lib.RED_ERR | lib.RED_SUM)
+            lv.sweep(1, RED)
         fetch = lv.result
-        cells_per_step = n ** 3
+        local_cells = total_cells = n ** 3
+        workload = (f"config 3: {n}x{n}x{n} mixed periodic/Neumann/Dirichlet, 2 plate electrodes + rho=3 block, "
+                    f"finest level, one red-black SOR sweep with fused err/sum reductions per step")
+        scaling = "weak"
     else:
         from multigrid_amd import slab
-        text = config3_input((n, n, n * world), tol=args.vcycle_tol, sor=args.sor)
+        cfg = args.config or 5
+        if cfg == 5:
+            dims = (2048, 2048, 2048) if not args.dist_size else (args.dist_size,) * 3
+            text = config5_input(dims, tol=args.vcycle_tol, sor=args.sor)
+            name = f"config 5: {dims[0]}x{dims[1]}x{dims[2]} fully periodic, 2 plate electrodes"
+        elif cfg == 4:
+            dims = (256, 256, 4096) if not args.dist_size else (args.dist_size, args.dist_size, 16 * args.dist_size)
+            text = config4_input(dims, tol=args.vcycle_tol, sor=args.sor)
+            name = f"config 4: {dims[0]}x{dims[1]}x{dims[2]} elongated, electrodes at the z ends"
+        else:
+            raise SystemExit("--config 4 or 5")
         top = mgio.iomg_read(mgio.MgIO(text=text))
         sl = slab.SlabLevel(ctx, top, rank, world, overlap=not args.no_overlap)
         sl.setup(True)
         step = sl.sweep
         fetch = sl.result
-        cells_per_step = n ** 3 * world
+        total_cells = dims[0] * dims[1] * dims[2]
+        local_cells = dims[0] * dims[1] * sl.n3
+        workload = (f"{name}, finest level in {world} z slabs, one red-black SOR sweep with fused err/sum reductions "
+                    f"and the halo exchange per step")
+        scaling = "strong"
 
     for _ in range(args.warmup):
         step()
@@ -221,16 +344,15 @@ def main():
     wall = float(dt.item())
     ms_per_step = wall / args.steps * 1e3
     kernel_ms = ev0.elapsed_time(ev1) / args.steps          # device time of one sweep on the kernel's stream
-    glups = cells_per_step / (wall / args.steps) / 1e9
-    achieved = BYTES_PER_LUP * (n ** 3) / (kernel_ms * 1e-3) / 1e9   # per GPU
+    glups = total_cells / (wall / args.steps) / 1e9
+    achieved = BYTES_PER_LUP * local_cells / (kernel_ms * 1e-3) / 1e9   # per GPU
 
     out = {
         "metric": METRIC, "value": glups, "unit": "GLUP/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f64",
+        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": scaling, "vs_baseline": None, "dtype": "f64",
         "data": "synthetic",
-        "config": {"workload": f"config 3: {n}x{n}x{n * world} mixed periodic/Neumann/Dirichlet, 2 plate electrodes + rho=3 block, "
-                               f"finest level, one red-black SOR sweep with fused err/sum reductions per step",
-                   "parallelism": "single GPU" if world == 1 else f"z-slab x{world}", "sor": float(args.sor)},
+        "config": {"workload": workload, "parallelism": "single GPU" if world == 1 else f"z-slab x{world}",
+                   "sor": float(args.sor)},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                      "frac": achieved / HBM_PEAK_GBS, "traffic": None,
                      "kernel_ms": kernel_ms, "bytes_per_lup": BYTES_PER_LUP},
@@ -248,7 +370,8 @@ def main():
                 whole.set_boxes(*G.box_table(top))
                 whole.bring_back()
                 whole.setup(True)
-                whole.sweep(args.warmup + args.steps, lib.RED_ERR | lib.RED_SUM)
+                for _ in range(args.warmup + args.steps):
+                    whole.sweep(1, RED)
                 we2, ws, _ = whole.result()
                 whole.close()
                 out["check"]["undivided"] = {"err_sq_max": we2, "abs_sum": ws, "identical": bool(we2 == e2 and ws == s)}
@@ -256,11 +379,24 @@ def main():
                 out["check"]["undivided"] = {"error": str(e)}
         barrier()
     tr = os.path.join(ROOT, "profiles", "traffic.json")
-    if os.path.exists(tr):
+    if os.path.exists(tr) and world == 1:
         try:
             out["roofline"]["traffic"] = json.load(open(tr)).get("hbm_bytes_per_launch")
         except Exception:
             pass
+
+    if world == 1:
+        # two sweeps in one pass over the field (mgx_level_sweep(lv, 2, ...): the form gs_V's legs take), reductions on
+        # the second sweep as the legs ask for them; 16 B of algorithmic traffic per cell per PASS
+        def pair():
+            lv.sweep(2, lib.RED_ERR)
+        for _ in range(3):
+            pair()
+        pk, _ = timed(pair, max(5, args.steps // 2))
+        out["roofline"]["pair_pass"] = {"kernel_ms": pk, "sweeps_per_pass": 2, "bytes_per_cell_per_pass": BYTES_PER_LUP,
+                                        "achieved": BYTES_PER_LUP * local_cells / (pk * 1e-3) / 1e9,
+                                        "frac": BYTES_PER_LUP * local_cells / (pk * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                        "glups": 2 * local_cells / (pk * 1e-3) / 1e9}
 
     if world == 1 and not args.no_vcycle:
         # complete `method v-cycle` solve of the same input (fresh state), timed to its own tolerance
@@ -286,16 +422,19 @@ def main():
                          "final_err": float(h["err"][-1]) if len(h) else None,
                          "lattice_updates": int(sum(int(g.itt) * int(np.prod(g.n)) for g in top.levels()))}
         if status == "converged":
-            # the timed steps above start from the set-up state (most of the field still zero); the same step on the
-            # converged potential, for comparison: sweep time depends on the values (bit activity), not on the path
+            # the timed steps above start from the set-up state (most of the field still zero); the same launches on the
+            # converged potential: sweep time depends on the values (bit activity), not on the path
             for _ in range(3):
                 step()
-            torch.cuda.synchronize()
-            ts0 = time.perf_counter()
-            for _ in range(20):
-                step()
-            torch.cuda.synchronize()
-            out["vcycle"]["ms_per_step_on_solution"] = (time.perf_counter() - ts0) / 20 * 1e3
+            sk, sw = timed(step, 20)
+            out["vcycle"]["ms_per_step_on_solution"] = sw
+            ach = BYTES_PER_LUP * local_cells / (sk * 1e-3) / 1e9
+            out["roofline"]["on_solution"] = {"kernel_ms": sk, "achieved": ach, "frac": ach / HBM_PEAK_GBS}
+            for _ in range(3):
+                pair()
+            pk, _ = timed(pair, 10)
+            out["roofline"]["pair_pass"]["on_solution"] = {"kernel_ms": pk, "glups": 2 * local_cells / (pk * 1e-3) / 1e9,
+                                                           "frac": BYTES_PER_LUP * local_cells / (pk * 1e-3) / 1e9 / HBM_PEAK_GBS}
     exe = os.path.join(ROOT, "multigrid_amd", "fortran", "mg_gpu_f64")
     if world == 1 and not args.no_vcycle and not args.no_fortran_host and os.path.exists(exe):
         # the same solve driven by the Fortran host (the reference's cycle control over the C ABI, ISO_C_BINDING), as
@@ -312,27 +451,31 @@ def main():
                                               "sweeps_per_level": per[0] if per else None}
             except Exception as e:
                 out["vcycle_fortran_host"] = {"seconds": None, "error": str(e)}
-    if world > 1 and args.dist_vcycle:
-        # the same solve with every level of the hierarchy as z slabs aligned between levels: transfers are local,
-        # each is followed by one halo refresh, reductions are all-reduced (exact sum: identical on every rank)
+    if world > 1 and not args.no_dist_vcycle:
+        # the headline solve (config 3, tol 1e-8) with every level of the hierarchy as z slabs aligned between levels over
+        # the N GPUs: transfers are local, each is followed by one halo refresh, reductions are all-reduced (exact
+        # sum: identical on every rank), thin coarse levels are held whole by every rank
         sl.lv.close()
-        dsolver = slab.SlabSolver.build(top, ctx, rank, world, overlap=not args.no_overlap, print_sums=False,
-                                        max_sweeps=200000)
-        barrier()
-        tv0 = time.perf_counter()
+        n3 = args.n if not args.dist_size else args.dist_size
+        vtop = mgio.iomg_read(mgio.MgIO(text=config3_input((n3, n3, n3), tol=args.vcycle_tol, sor=args.sor)))
         status = "converged"
         try:
+            dsolver = slab.SlabSolver.build(vtop, ctx, rank, world, overlap=not args.no_overlap, print_sums=False,
+                                            max_sweeps=200000)
+            barrier()
+            tv0 = time.perf_counter()
             dsolver.mg_gs_cds(cycle.CDS_W_CYCLE)
+            barrier()
+            tv = time.perf_counter() - tv0
+            h = dsolver.history_array()
+            out["vcycle"] = {"seconds": tv, "status": status, "tol": float(args.vcycle_tol),
+                             "workload": f"config 3: {n3}^3 over {world} z slabs",
+                             "sweeps_per_level": [int(g.itt) for g in vtop.levels()],
+                             "levels": [[int(v) for v in g.n] for g in vtop.levels()],
+                             "final_err": float(h["err"][-1]) if len(h) else None,
+                             "lattice_updates": int(sum(int(g.itt) * int(np.prod(g.n)) for g in vtop.levels()))}
         except Exception as e:
-            status = f"stopped: {e}"
-        barrier()
-        tv = time.perf_counter() - tv0
-        h = dsolver.history_array()
-        out["vcycle"] = {"seconds": tv, "status": status, "tol": float(args.vcycle_tol),
-                         "sweeps_per_level": [int(g.itt) for g in top.levels()],
-                         "levels": [[int(v) for v in g.n] for g in top.levels()],
-                         "final_err": float(h["err"][-1]) if len(h) else None,
-                         "lattice_updates": int(sum(int(g.itt) * int(np.prod(g.n)) for g in top.levels()))}
+            out["vcycle"] = {"seconds": None, "status": f"stopped: {e}", "tol": float(args.vcycle_tol)}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline()
     if rank == 0:

@@ -122,6 +122,16 @@ int mgx_level_sweep_part(mgx_level *lv, int part, int reduce);
  * inclusive) — the building block for halo-exchange overlap across z-slabs.
  * Reductions accumulate into the level's result until mgx_level_result_reset. */
 int mgx_level_half_sweep(mgx_level *lv, int parity, int32_t zlo, int32_t zhi, int reduce);
+/* grid_solve's loop (m_gs_CDS.F90:200-216) run from the device side: sweeps with both reductions are repeated until
+ * tol = |old_sum - new_sum| * nr (nr = 1/count_nonconst, everything in the level's precision, :191,206-207) no longer
+ * exceeds tol_level; the test is evaluated by a kernel after every sweep, so the host waits once per batch of sweeps
+ * instead of once per sweep.  old_sum = grid_sum of the level as it stands (:195).  hist receives (tol, new_sum,
+ * max (vv-V)^2) per sweep (the numbers grid_solve prints, :209-210), up to hist_cap sweeps; *nsweeps = sweeps done;
+ * *status = 0 converged, 1 max_sweeps reached, 2 a value left the exact range of the sum (|V| >= 2^20 or not
+ * finite).  Sweep counts, fields and history are those of the host loop over mgx_level_sweep + mgx_level_result.
+ * Undivided levels on the fused kernel only (MGX_ESTATE otherwise: loop on the host). [sync] */
+int mgx_level_solve(mgx_level *lv, double tol_level, int64_t count_nonconst, double old_sum, int64_t max_sweeps,
+                    int64_t hist_cap, double *hist, int64_t *nsweeps, int32_t *status);
 int mgx_level_result_reset(mgx_level *lv);
 /* [sync] results of the last sweep: err_sq_max = max (vv-V)^2 (grid%err**2 before the sqrt
  * of m_gs_CDS.F90:313), abs_sum as mgx_level_abs_sum.  Either pointer may be NULL.

@@ -66,6 +66,7 @@ struct mgx_ctx {
   bool own_stream = false;
   int kernel = MGX_KERNEL_AUTO;
   u64 *h_res = nullptr;        // pinned read-back buffer
+  double *h_solve = nullptr;   // pinned read-back buffer of mgx_level_solve (state + one batch of history)
   hipStream_t aux = nullptr;   // side stream: box tiles of the fused sweep run beside the others
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
 };
@@ -92,6 +93,7 @@ struct mgx_level {
   int nbox = 0;
   long long count_cache = -1;
   u64 *d_res = nullptr;        // MGX_RES_WORDS words
+  MgxSolveState *d_solve = nullptr;   // state + history of mgx_level_solve (allocated on first use)
   MgxFusedPlan plan;           // tile lists of the fused sweep (rebuilt when the boxes change)
   MgxFusedPlan plan2;          // tile lists of the two-sweeps-per-pass kernel
   std::vector<struct MgxTransferPlan *> transfers;   // index tables of transfers INTO this level, by source geometry
@@ -189,6 +191,7 @@ extern "C" int mgx_ctx_destroy(mgx_ctx *ctx) {
   if (ctx->ev_join) (void)hipEventDestroy(ctx->ev_join);
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
   if (ctx->h_res) (void)hipHostFree(ctx->h_res);
+  if (ctx->h_solve) (void)hipHostFree(ctx->h_solve);
   delete ctx;
   return MGX_OK;
 }
@@ -269,6 +272,7 @@ extern "C" int mgx_level_destroy(mgx_level *lv) {
   (void)hipFree(lv->buf[0]);
   (void)hipFree(lv->buf[1]);
   (void)hipFree(lv->d_res);
+  if (lv->d_solve) (void)hipFree(lv->d_solve);
   if (lv->d_boxes) (void)hipFree(lv->d_boxes);
   if (lv->plan.d_tiles) (void)hipFree(lv->plan.d_tiles);
   if (lv->plan2.d_tiles) (void)hipFree(lv->plan2.d_tiles);
@@ -576,6 +580,89 @@ extern "C" int mgx_level_half_sweep(mgx_level *lv, int parity, int32_t zlo, int3
   TRY(set_device(C(lv)));
   TRY(materialize(lv));
   return lv->elem == 4 ? launch_half<float>(lv, parity, zlo, zhi, reduce) : launch_half<double>(lv, parity, zlo, zhi, reduce);
+}
+
+// grid_solve's loop (m_gs_CDS.F90:200-216) without a host round trip per sweep: batches of sweeps are enqueued, each
+// followed by a one-block kernel that evaluates the convergence test on the device and, once it is met, raises a flag
+// that voids the sweeps still queued behind it.  The host reads one small record per batch.
+#define MGX_SOLVE_BATCH 24
+template <typename T>
+static int do_solve(mgx_level *lv, double tol_level, double nr, double old_sum, long long max_sweeps, long long hist_cap,
+                    double *hist, long long *nsweeps, int *status) {
+  mgx_ctx *c = C(lv);
+  const MgxGeom &g = lv->g;
+  hipStream_t st = c->stream;
+  if (!lv->d_solve) HIP_TRY(hipMalloc((void **)&lv->d_solve, sizeof(MgxSolveState) + sizeof(double) * 3 * MGX_SOLVE_BATCH));
+  if (!c->h_solve) HIP_TRY(hipHostMalloc((void **)&c->h_solve, sizeof(MgxSolveState) + sizeof(double) * 3 * MGX_SOLVE_BATCH, hipHostMallocDefault));
+  double *d_hist = reinterpret_cast<double *>(lv->d_solve + 1);
+  TRY(sync_shell<T>(lv));
+  if (!lv->plan.valid && mgx_fused_make_plan(lv->plan, g, lv->boxes, st) != 0)
+    return fail(MGX_EHIP, "mgx_level_solve: could not build the tile lists of the fused kernel");
+  MgxSolveState init;
+  init.stop = 0; init.count = 0; init.old_sum = (double)(T)old_sum;
+  HIP_TRY(hipMemcpyAsync(lv->d_solve, &init, sizeof init, hipMemcpyHostToDevice, st));
+  HIP_TRY(hipStreamSynchronize(st));                       // `init` is a local
+  TRY(reset_result(lv));
+  const MgxSweepParams<T> p = make_params<T>(lv);
+  long long done = 0;
+  *status = 0;
+  for (;;) {
+    const int batch = (int)std::min<long long>(MGX_SOLVE_BATCH, max_sweeps - done);
+    if (batch <= 0) { *status = 1; break; }
+    const int cur0 = lv->cur;
+    for (int j = 0; j < batch; ++j) {
+      const int a = cur0 ^ (j & 1);
+      if (mgx_fused_launch(lv->plan, 0, (const T *)lv->buf[a], (T *)lv->buf[1 - a], g, p, lv->d_boxes, lv->nbox,
+                           MGX_RED_ERR | MGX_RED_SUM, lv->d_res, st, &lv->d_solve->stop) != 0)
+        return fail(MGX_EHIP, "mgx_level_solve: fused kernel launch configuration failed");
+      hipLaunchKernelGGL((k_solve_check<T>), dim3(1), dim3(MGX_RES_SLOTS), 0, st, lv->d_res, lv->d_solve, d_hist, MGX_SOLVE_BATCH,
+                         tol_level, nr);
+    }
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipMemcpyAsync(c->h_solve, lv->d_solve, sizeof(MgxSolveState) + sizeof(double) * 3 * batch, hipMemcpyDeviceToHost, st));
+    HIP_TRY(hipStreamSynchronize(st));
+    const MgxSolveState *hs = reinterpret_cast<const MgxSolveState *>(c->h_solve);
+    const double *hh = reinterpret_cast<const double *>(hs + 1);
+    const int cnt = hs->count;
+    for (int i = 0; i < cnt; ++i)
+      if (done + i < hist_cap)
+        for (int k = 0; k < 3; ++k) hist[3 * (done + i) + k] = hh[3 * i + k];
+    done += cnt;
+    lv->cur = cur0 ^ (cnt & 1);                             // the sweeps behind the flag left the buffers alone
+    if (hs->stop == 2) { *status = 2; break; }
+    if (hs->stop == 1) break;
+    HIP_TRY(hipMemsetAsync(&lv->d_solve->count, 0, sizeof(int), st));   // next batch: history from slot 0 again
+  }
+  *nsweeps = done;
+  return MGX_OK;
+}
+
+extern "C" int mgx_level_solve(mgx_level *lv, double tol_level, int64_t count_nonconst, double old_sum, int64_t max_sweeps,
+                               int64_t hist_cap, double *hist, int64_t *nsweeps, int32_t *status) {
+  if (!lv || !nsweeps || !status || (hist_cap > 0 && !hist)) return fail(MGX_EINVAL, "mgx_level_solve: NULL argument");
+  if (count_nonconst < 1 || max_sweeps < 0 || hist_cap < 0) return fail(MGX_EINVAL, "mgx_level_solve: count %lld, max_sweeps %lld", (long long)count_nonconst, (long long)max_sweeps);
+  if (!lv->params_set) return fail(MGX_ESTATE, "mgx_level_solve: mgx_level_set_params not called");
+  if (!lv->defined) return fail(MGX_ESTATE, "mgx_level_solve: level %d was released", lv->layer);
+  if (lv->inner_pending) return fail(MGX_ESTATE, "mgx_level_solve: the inner part of a split sweep is still due");
+  if (lv->g.n3 != lv->g.n3g) return fail(MGX_ESTATE, "mgx_level_solve: a slab needs a halo exchange between sweeps: loop on the host");
+  const bool ok = lv->elem == 4 ? mgx_fused_supported<float>(lv->g, lv->nbox) : mgx_fused_supported<double>(lv->g, lv->nbox);
+  if (!ok || C(lv)->kernel == MGX_KERNEL_TWO_PASS)
+    return fail(MGX_ESTATE, "mgx_level_solve: needs the fused kernel (at most %d boxes, kernel not forced to two-pass): loop on the host", MGX_MAX_FUSED_BOXES);
+  TRY(set_device(C(lv)));
+  TRY(materialize(lv));
+  long long n = 0;
+  int stt = 0;
+  int rc;
+  if (lv->elem == 4) {
+    const float nr = 1.0f / (float)count_nonconst;          // nr = 1._grid_p / grid_non_constant_elem (m_gs_CDS.F90:191)
+    rc = do_solve<float>(lv, tol_level, (double)nr, old_sum, max_sweeps, hist_cap, hist, &n, &stt);
+  } else {
+    const double nr = 1.0 / (double)count_nonconst;
+    rc = do_solve<double>(lv, tol_level, nr, old_sum, max_sweeps, hist_cap, hist, &n, &stt);
+  }
+  *nsweeps = n;
+  *status = stt;
+  return rc;
 }
 
 // 128-bit integer (units 2^-72) -> nearest-even double

@@ -578,9 +578,13 @@ __global__ __launch_bounds__((NW + 1) * 64) void k_fused_sweep(const T *__restri
                                                      const MgxSweepParams<T> p, const MgxBox *__restrict__ bx,
                                                      const int nb, const int ntx,
                                                      const int *__restrict__ tiles, const int n_box, const int n_const,
-                                                     const int reduce, u64 *__restrict__ res) {
+                                                     const int reduce, u64 *__restrict__ res,
+                                                     const int *__restrict__ stop) {
   constexpr int TXP = 64;
   extern __shared__ __align__(16) unsigned char mgx_lds_raw[];
+  // a sweep enqueued ahead of the convergence test that may make it void (mgx_level_solve): it leaves at once when
+  // the kernel that evaluated the test has raised the flag (same stream, an earlier kernel: plain load)
+  if (stop != nullptr && *stop != 0) return;
   T *lds = reinterpret_cast<T *>(mgx_lds_raw);          // [slot 0..2][black, red][pairs of a staged plane]
   MgxBoxLds<T> *bl = reinterpret_cast<MgxBoxLds<T> *>(lds + 3 * 2 * (TXP + 2) * (TY + 6));
 
@@ -598,7 +602,8 @@ __global__ __launch_bounds__((NW + 1) * 64) void k_fused_sweep(const T *__restri
 
 template <typename T, int TY, int NW>
 static int mgx_fused_launch_cfg(const MgxFusedPlan &pl, int part, const T *src, T *dst, const MgxGeom &g,
-                                const MgxSweepParams<T> &p, const MgxBox *bx, int nb, int reduce, u64 *res, hipStream_t st) {
+                                const MgxSweepParams<T> &p, const MgxBox *bx, int nb, int reduce, u64 *res, hipStream_t st,
+                                const int *stop) {
   constexpr int TXP = 64;
   constexpr size_t lds = (size_t)3 * 2 * (TXP + 2) * (TY + 6) * sizeof(T) + sizeof(MgxBoxLds<T>);
   if (lds > 64 * 1024) {        // beyond the default dynamic LDS limit: raise it once per device and function
@@ -616,16 +621,17 @@ static int mgx_fused_launch_cfg(const MgxFusedPlan &pl, int part, const T *src, 
   const int total = tl.n_box + tl.n_const + tl.n_fast;
   if (total > 0)
     hipLaunchKernelGGL((k_fused_sweep<T, TY, NW>), dim3((unsigned)total), dim3((NW + 1) * 64), lds, st, src, dst, g, p, bx, nb,
-                       pl.ntx, pl.d_tiles + 3 * tl.offset, tl.n_box, tl.n_const, reduce, res);
+                       pl.ntx, pl.d_tiles + 3 * tl.offset, tl.n_box, tl.n_const, reduce, res, stop);
   return 0;
 }
 
 template <typename T>
 static int mgx_fused_launch_t(const MgxFusedPlan &pl, int part, const T *src, T *dst, const MgxGeom &g,
-                            const MgxSweepParams<T> &p, const MgxBox *bx, int nb, int reduce, u64 *res, hipStream_t st) {
+                            const MgxSweepParams<T> &p, const MgxBox *bx, int nb, int reduce, u64 *res, hipStream_t st,
+                            const int *stop) {
   switch (pl.ty * 100 + pl.nw) {
-    case 1208: return mgx_fused_launch_cfg<T, 12, 8>(pl, part, src, dst, g, p, bx, nb, reduce, res, st);
-    case 2008: return mgx_fused_launch_cfg<T, 20, 8>(pl, part, src, dst, g, p, bx, nb, reduce, res, st);
-    default: return mgx_fused_launch_cfg<T, 8, 4>(pl, part, src, dst, g, p, bx, nb, reduce, res, st);
+    case 1208: return mgx_fused_launch_cfg<T, 12, 8>(pl, part, src, dst, g, p, bx, nb, reduce, res, st, stop);
+    case 2008: return mgx_fused_launch_cfg<T, 20, 8>(pl, part, src, dst, g, p, bx, nb, reduce, res, st, stop);
+    default: return mgx_fused_launch_cfg<T, 8, 4>(pl, part, src, dst, g, p, bx, nb, reduce, res, st, stop);
   }
 }

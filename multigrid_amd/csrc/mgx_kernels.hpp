@@ -91,6 +91,95 @@ __global__ __launch_bounds__(MGX_RES_SLOTS) void k_fold_result(u64 *__restrict__
 #endif
 
 // ------------------------------------------------------------------------------------------------
+// grid_solve's convergence test on the device (m_gs_CDS.F90:200-216)
+
+// 128-bit integer (units 2^-72) -> nearest-even double, as mgx_limbs_to_double on the host
+__device__ inline double mgx_limbs_to_double_dev(const u64 lo, const u64 hi) {
+  if (lo == 0 && hi == 0) return 0.0;
+  const int msb = hi ? 127 - __clzll((long long)hi) : 63 - __clzll((long long)lo);
+  if (msb <= 52) return ldexp((double)lo, -MGX_SUM_Q);
+  const int drop = msb - 52;                         // 1 .. 75
+  u64 mant, rem_hi, rem_lo, half_hi, half_lo;
+  if (drop >= 64) {
+    mant = hi >> (drop - 64);
+    rem_hi = drop == 64 ? 0ull : (hi & ((1ull << (drop - 64)) - 1ull));
+    rem_lo = lo;
+    half_hi = drop == 64 ? 0ull : (1ull << (drop - 65));
+    half_lo = drop == 64 ? (1ull << 63) : 0ull;
+  } else {
+    mant = (lo >> drop) | (hi << (64 - drop));      // hi << (64 - drop) keeps the bits that fall below 2^64
+    rem_hi = 0ull;
+    rem_lo = lo & ((1ull << drop) - 1ull);
+    half_hi = 0ull;
+    half_lo = 1ull << (drop - 1);
+  }
+  const bool above = rem_hi > half_hi || (rem_hi == half_hi && rem_lo > half_lo);
+  const bool tie = rem_hi == half_hi && rem_lo == half_lo;
+  if (above || (tie && (mant & 1ull))) mant += 1ull;
+  return ldexp((double)mant, drop - MGX_SUM_Q);
+}
+
+struct MgxSolveState {      // device memory, one per level that mgx_level_solve has run on
+  int stop;                 // 0: keep sweeping; 1: the test was met; 2: the sum left its exact range
+  int count;                // sweeps of this batch that took effect
+  double old_sum;           // grid_sum before the next sweep, already rounded to the level's precision
+};
+
+// After a sweep with both reductions: fold the result replicas, evaluate tol = |old_sum - new_sum| * nr in the level's
+// precision T (m_gs_CDS.F90:206-207), append (tol, new_sum, max dV^2) to the batch's history and raise `stop` when
+// the loop condition `tol > gtol` (:200) fails.  While the loop goes on the replicas are cleared for the next sweep;
+// when it ends the folded result is left in replica 1 (a later fold finds it).  One block of MGX_RES_SLOTS threads.
+template <typename T>
+__global__ __launch_bounds__(MGX_RES_SLOTS) void k_solve_check(u64 *__restrict__ res, MgxSolveState *__restrict__ stt,
+                                                               double *__restrict__ hist, const int cap, const double gtol,
+                                                               const double nr) {
+  if (stt->stop != 0) return;
+  __shared__ u64 sh[MGX_RES_SLOTS / 64][6];
+  u64 *mine = res + MGX_RES_WORDS * (1 + threadIdx.x);
+  u64 m = mine[0];
+  u64 d[5];
+#pragma unroll
+  for (int k = 0; k < 5; ++k) d[k] = mine[1 + k];
+#pragma unroll
+  for (int k = 0; k < 6; ++k) mine[k] = 0ull;
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { const u64 t = __shfl_xor(m, o, 64); m = t > m ? t : m; }
+#pragma unroll
+  for (int k = 0; k < 5; ++k) d[k] = mgx_wave_add(d[k]);
+  const int w = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) { sh[w][0] = m; for (int k = 0; k < 5; ++k) sh[w][1 + k] = d[k]; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    u64 mm = sh[0][0], dd[5] = {sh[0][1], sh[0][2], sh[0][3], sh[0][4], sh[0][5]};
+    for (int i = 1; i < MGX_RES_SLOTS / 64; ++i) {
+      mm = sh[i][0] > mm ? sh[i][0] : mm;
+      for (int k = 0; k < 5; ++k) dd[k] += sh[i][1 + k];
+    }
+    // positional sum of the four digits (they may exceed 32 bits)
+    u64 lo = dd[0], hi = dd[2] + (dd[3] << 32);
+    const u64 a = dd[1] << 32;
+    lo += a;
+    hi += (dd[1] >> 32) + (lo < a ? 1ull : 0ull);
+    const bool bad = dd[4] != 0ull;
+    const double sum = bad ? __longlong_as_double(0x7ff8000000000000LL) : mgx_limbs_to_double_dev(lo, hi);
+    const T new_sum = (T)sum, old_sum = (T)stt->old_sum;
+    const T diff = old_sum - new_sum;
+    const T tol = (diff < (T)0 ? -diff : diff) * (T)nr;
+    const int i = stt->count;
+    if (i < cap) { hist[3 * i] = (double)tol; hist[3 * i + 1] = (double)new_sum; hist[3 * i + 2] = __longlong_as_double((long long)mm); }
+    stt->count = i + 1;
+    stt->old_sum = (double)new_sum;
+    const int stop = bad ? 2 : ((double)tol > gtol ? 0 : 1);
+    stt->stop = stop;
+    if (stop) {                        // leave the last sweep's result where mgx_level_result finds it
+      u64 *r1 = res + MGX_RES_WORDS;
+      r1[0] = mm;
+      for (int k = 0; k < 5; ++k) r1[1 + k] = dd[k];
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------
 // box predicates (t_mg.f90:634-710) on the device table; coordinates are GLOBAL
 
 __device__ inline bool mgx_in_box(const MgxBox &b, int x, int y, int z) {

@@ -155,22 +155,27 @@ static bool mgx_fused_supported(const MgxGeom &g, int nbox) {
 
 
 // launchers (mgx_fused_k.hip, mgx_tb_k.hip); return 0 or -1 (launch configuration failed)
+// (stop: device flag that voids the sweep when non-zero, or NULL)
 int mgx_fused_launch_f64(const MgxFusedPlan &pl, int part, const double *src, double *dst, const MgxGeom &g,
-                         const MgxSweepParams<double> &p, const MgxBox *bx, int nb, int reduce, u64 *res, hipStream_t st);
+                         const MgxSweepParams<double> &p, const MgxBox *bx, int nb, int reduce, u64 *res, hipStream_t st,
+                         const int *stop);
 int mgx_fused_launch_f32(const MgxFusedPlan &pl, int part, const float *src, float *dst, const MgxGeom &g,
-                         const MgxSweepParams<float> &p, const MgxBox *bx, int nb, int reduce, u64 *res, hipStream_t st);
+                         const MgxSweepParams<float> &p, const MgxBox *bx, int nb, int reduce, u64 *res, hipStream_t st,
+                         const int *stop);
 int mgx_tb2_launch_f64(const MgxFusedPlan &pl, const double *src, double *dst, const MgxGeom &g,
                        const MgxSweepParams<double> &p, const MgxBox *bx, int nb, int reduce, u64 *res, hipStream_t st);
 int mgx_tb2_launch_f32(const MgxFusedPlan &pl, const float *src, float *dst, const MgxGeom &g,
                        const MgxSweepParams<float> &p, const MgxBox *bx, int nb, int reduce, u64 *res, hipStream_t st);
 
 inline int mgx_fused_launch(const MgxFusedPlan &pl, int part, const double *src, double *dst, const MgxGeom &g,
-                            const MgxSweepParams<double> &p, const MgxBox *bx, int nb, int reduce, u64 *res, hipStream_t st) {
-  return mgx_fused_launch_f64(pl, part, src, dst, g, p, bx, nb, reduce, res, st);
+                            const MgxSweepParams<double> &p, const MgxBox *bx, int nb, int reduce, u64 *res, hipStream_t st,
+                            const int *stop = nullptr) {
+  return mgx_fused_launch_f64(pl, part, src, dst, g, p, bx, nb, reduce, res, st, stop);
 }
 inline int mgx_fused_launch(const MgxFusedPlan &pl, int part, const float *src, float *dst, const MgxGeom &g,
-                            const MgxSweepParams<float> &p, const MgxBox *bx, int nb, int reduce, u64 *res, hipStream_t st) {
-  return mgx_fused_launch_f32(pl, part, src, dst, g, p, bx, nb, reduce, res, st);
+                            const MgxSweepParams<float> &p, const MgxBox *bx, int nb, int reduce, u64 *res, hipStream_t st,
+                            const int *stop = nullptr) {
+  return mgx_fused_launch_f32(pl, part, src, dst, g, p, bx, nb, reduce, res, st, stop);
 }
 inline int mgx_tb2_launch(const MgxFusedPlan &pl, const double *src, double *dst, const MgxGeom &g,
                           const MgxSweepParams<double> &p, const MgxBox *bx, int nb, int reduce, u64 *res, hipStream_t st) {

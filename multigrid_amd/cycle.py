@@ -26,13 +26,14 @@ class Solver:
     """Owns the device context and the resident levels of one hierarchy."""
 
     def __init__(self, top: G.MgGrid, device: int = 0, stream: Optional[int] = None, ctx: Optional[lib.Context] = None,
-                 verbose: bool = False, print_sums: bool = True, max_sweeps: int = 1 << 24):
+                 verbose: bool = False, print_sums: bool = True, max_sweeps: int = 1 << 24, device_loop: bool = True):
         self.top = top
         self.ctx = ctx if ctx is not None else lib.Context(device, stream)
         self.own_ctx = ctx is None
         self.verbose = verbose
         self.print_sums = print_sums       # evaluate the print-only sums of gs_V (m_gs_CDS.F90:238,245,269,275)
         self.max_sweeps = max_sweeps
+        self.device_loop = device_loop     # grid_solve's loop through mgx_level_solve (test evaluated on the device)
         self.history: List[tuple] = []
         self.total_sweeps = 0
         self.t = top.dtype.type
@@ -170,12 +171,46 @@ class Solver:
         old_sum = self.grid_sum(grid)
         self.say(f"Initial sum: {float(old_sum * nr):10.7f}")
         old_itt = grid.itt
+        if self.device_loop and self.solve_on_device(grid, nr, gtol, old_sum, old_itt):
+            return
         while tol > gtol:
             new_sum = self.gs_steps(grid, 1, True)
             tol = t(abs(t(old_sum - new_sum)) * nr)
             old_sum = new_sum
             self.record(grid, 0, tol, new_sum)
             self.say(f" itt {grid.itt - old_itt:6d} {float(tol):10.7f} {float(new_sum * nr):10.7f} {self.level_err(grid):10.7f}")
+
+    def solve_on_device(self, grid, nr, gtol, old_sum, old_itt) -> bool:
+        """the loop of grid_solve (m_gs_CDS.F90:200-216) with the convergence test evaluated on the device: the same
+        sweeps, history and prints, one host wait per batch of sweeps.  False = the level does not offer it (a slab, a
+        test double) or the library does not take it (more than 32 boxes): the caller loops itself."""
+        solve = getattr(grid.dev, "solve", None)
+        if solve is None:
+            return False
+        t = self.t
+        budget = self.max_sweeps - self.total_sweeps
+        if budget <= 0:
+            raise G.MgStop(f"more than {self.max_sweeps} sweeps")
+        try:
+            hist, n, status = solve(float(gtol), self.count(grid), float(old_sum), budget)
+        except lib.MgxError as e:
+            if e.code == -4:              # MGX_ESTATE: not on this level
+                return False
+            raise
+        for tol_, sum_, e2 in hist:
+            grid.itt += 1
+            self.total_sweeps += 1
+            grid.err = float(np.sqrt(t(e2)))
+            grid.err_pending = False
+            if sum_ != sum_:
+                break
+            self.record(grid, 0, t(tol_), t(sum_))
+            self.say(f" itt {grid.itt - old_itt:6d} {float(t(tol_)):10.7f} {float(t(sum_) * nr):10.7f} {grid.err:10.7f}")
+        if status == 2:
+            raise G.MgStop(f"layer {grid.layer}: |V| reached 2^20 or is not finite after {grid.itt} sweeps: the iteration diverges")
+        if status == 1:
+            raise G.MgStop(f"more than {self.max_sweeps} sweeps")
+        return True
 
     def _leg(self, grid, want_sum: bool = False):
         """steps × gs_step between two (print-only) sums: m_gs_CDS.F90:237-248 / :268-278.  Returns the grid_sum

@@ -8,7 +8,8 @@ module mgx_c
 
   integer(c_int), parameter :: MGX_RED_ERR = 1, MGX_RED_SUM = 2
   integer(c_int), parameter :: MGX_PART_EDGE = 1, MGX_PART_INNER = 2
-  integer(c_int), parameter :: MGX_KERNEL_AUTO = 0, MGX_KERNEL_TWO_PASS = 1, MGX_KERNEL_FUSED = 2
+  integer(c_int), parameter :: MGX_KERNEL_AUTO = 0, MGX_KERNEL_TWO_PASS = 1, MGX_KERNEL_FUSED = 2, MGX_KERNEL_PAIR = 3
+  integer(c_int), parameter :: MGX_OK = 0, MGX_EINVAL = -1, MGX_EHIP = -2, MGX_ENOMEM = -3, MGX_ESTATE = -4, MGX_ELIMIT = -5
 
   interface
      function mgx_last_error() bind(C, name="mgx_last_error") result(msg)
@@ -137,6 +138,17 @@ module mgx_c
        integer(c_int64_t), intent(out) :: limbs(2)         ! bit patterns of the two uint64_t words
        integer(c_int) :: rc
      end function mgx_level_abs_sum_limbs
+     function mgx_level_solve(lv, tol_level, count_nonconst, old_sum, max_sweeps, hist_cap, hist, nsweeps, status) &
+          bind(C, name="mgx_level_solve") result(rc)
+       import :: c_int, c_int32_t, c_int64_t, c_double, c_ptr
+       type(c_ptr), value :: lv
+       real(c_double), value :: tol_level, old_sum
+       integer(c_int64_t), value :: count_nonconst, max_sweeps, hist_cap
+       real(c_double), intent(out) :: hist(3, *)           ! (tol, new_sum, max dV^2) per sweep
+       integer(c_int64_t), intent(out) :: nsweeps
+       integer(c_int32_t), intent(out) :: status
+       integer(c_int) :: rc
+     end function mgx_level_solve
      function mgx_level_abs_sum_noalloc(lv, out_device) bind(C, name="mgx_level_abs_sum_noalloc") result(rc)
        import :: c_int, c_ptr
        type(c_ptr), value :: lv

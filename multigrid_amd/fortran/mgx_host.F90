@@ -55,6 +55,7 @@ module mgx_host
   type(host_history), public, save :: history
   logical, public, save :: print_sums = .true.     ! evaluate the print-only sums of gs_V (m_gs_CDS.F90:238,245,269,275)
   logical, public, save :: verbose = .false.
+  logical, public, save :: device_loop = .true.     ! grid_solve's convergence loop through mgx_level_solve where it applies
 
   public :: host_attach, host_detach
   public :: mg_gs_cds, gs_bottom_up, gs_w, gs_V, grid_solve
@@ -289,6 +290,9 @@ contains
     gtol = grid_tolerance(grid)
     tol = gtol + 1._grid_p
     old_sum = grid_sum(grid)
+    if ( device_loop ) then
+       if ( solve_on_device(grid, nr, gtol, old_sum) ) return
+    end if
     do while ( tol > gtol )
        call gs_steps(grid, 1, .true., new_sum)
        tol = abs(old_sum - new_sum) * nr
@@ -297,6 +301,41 @@ contains
        if ( verbose ) write(*,'(a,i6,3(tr1,f10.7))') ' itt ', grid%itt, tol, new_sum * nr, level_err(grid)
     end do
   end subroutine grid_solve
+
+  ! The loop of grid_solve (m_gs_CDS.F90:200-216) with the convergence test evaluated on the device (mgx_level_solve):
+  ! the same sweeps, history and prints, one host wait per batch of sweeps.  .false. = the library does not take this
+  ! level (a slab, more than 32 boxes): the caller loops itself.
+  function solve_on_device(grid, nr, gtol, old_sum) result(done)
+    type(host_grid), intent(inout) :: grid
+    real(grid_p), intent(in) :: nr, gtol, old_sum
+    logical :: done
+    integer(c_int64_t), parameter :: cap = 1048576_c_int64_t
+    real(c_double), allocatable :: hist(:,:)
+    integer(c_int64_t) :: n, i
+    integer(c_int32_t) :: status
+    integer(c_int) :: rc
+    real(grid_p) :: tol, new_sum
+    allocate(hist(3, cap))
+    rc = mgx_level_solve(grid%h, real(gtol, c_double), int(grid_non_constant_elem(grid), c_int64_t), real(old_sum, c_double), &
+         cap, cap, hist, n, status)
+    if ( rc == MGX_ESTATE ) then
+       done = .false.
+       return
+    end if
+    call mgx_check(rc)
+    do i = 1, n
+       grid%itt = grid%itt + 1
+       tol = real(hist(1, i), grid_p)
+       new_sum = real(hist(2, i), grid_p)
+       grid%err = sqrt(real(hist(3, i), grid_p))
+       grid%err_pending = .false.
+       call record(grid, 0, tol, new_sum)
+       if ( verbose ) write(*,'(a,i6,3(tr1,f10.7))') ' itt ', grid%itt, tol, new_sum * nr, grid%err
+    end do
+    if ( status == 2 ) stop 'mgx_host: |V| reached 2^20 or is not finite: the iteration diverges'
+    if ( status == 1 ) stop 'mgx_host: grid_solve did not meet its tolerance within 1048576 sweeps'
+    done = .true.
+  end function solve_on_device
 
   ! `steps` sweeps of one level between two print-only sums (m_gs_CDS.F90:237-248, :268-278)
   ! `s_end` = grid_sum after the last step, when `want_sum` asks for it (or the print-only sums are on)

@@ -27,7 +27,7 @@ SYMBOLS = [
     "mgx_level_set_params", "mgx_level_set_boxes", "mgx_level_setup", "mgx_level_sweep", "mgx_level_sweep_part",
     "mgx_level_half_sweep",
     "mgx_level_result_reset", "mgx_level_result", "mgx_level_abs_sum", "mgx_level_abs_sum_limbs",
-    "mgx_level_abs_sum_noalloc",
+    "mgx_level_abs_sum_noalloc", "mgx_level_solve",
     "mgx_limbs_to_double", "mgx_level_count_nonconst", "mgx_level_tolerance", "mgx_restrict", "mgx_prolong",
     "mgx_level_upload", "mgx_level_download", "mgx_level_plane_ptr", "mgx_level_halo_written", "mgx_level_info",
 ]
@@ -78,6 +78,7 @@ def load():
         "mgx_level_result": [vp, pdbl, pdbl, pu64],
         "mgx_level_abs_sum": [vp, pdbl], "mgx_level_abs_sum_limbs": [vp, pu64],
         "mgx_level_abs_sum_noalloc": [vp, vp],
+        "mgx_level_solve": [vp, dbl, i64, dbl, i64, i64, pdbl, C.POINTER(i64), pi32],
         "mgx_level_count_nonconst": [vp, C.POINTER(i64)],
         "mgx_level_tolerance": [vp, dbl, pdbl],
         "mgx_restrict": [vp, vp, C.c_int], "mgx_prolong": [vp, vp, C.c_int],
@@ -215,6 +216,16 @@ class DeviceLevel:
         limbs = (C.c_uint64 * 2)()
         _ck(self.L.mgx_level_abs_sum_limbs(self.h, limbs))
         return (int(limbs[1]) << 64) | int(limbs[0])
+
+    def solve(self, tol_level: float, count: int, old_sum: float, max_sweeps: int):
+        """grid_solve's loop with the convergence test on the device: (history array [n][3] of tol, sum, max dV^2;
+        status 0 converged / 1 max_sweeps / 2 sum out of range)"""
+        cap = int(max(1, min(max_sweeps, 1 << 20)))
+        hist = np.zeros((cap, 3), dtype=np.float64)
+        n, st = C.c_int64(), C.c_int32()
+        _ck(self.L.mgx_level_solve(self.h, float(tol_level), int(count), float(old_sum), int(max_sweeps), cap,
+                                   hist.ctypes.data_as(C.POINTER(C.c_double)), C.byref(n), C.byref(st)))
+        return hist[:min(n.value, cap)], int(n.value), int(st.value)
 
     def abs_sum_noalloc(self, out_device_ptr: int):
         """enqueue grid_sum without allocating or waiting; the three result words land at the DEVICE address given"""

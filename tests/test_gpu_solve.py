@@ -91,3 +91,39 @@ def test_cycle_without_print_only_sums(name, prec):
         assert bits_equal(top.dev.download(), V)
     finally:
         s.close()
+
+
+@pytest.mark.parametrize("prec", ["f32", "f64"])
+@pytest.mark.parametrize("name", ["solve_64_bu", "solve_80_bu"])
+def test_device_side_convergence_loop_equals_host_loop(name, prec):
+    """grid_solve's loop (m_gs_CDS.F90:200-216) through mgx_level_solve (test evaluated on the device, one host wait
+    per batch of sweeps) against the same loop on the host: identical sweep counts, history and field"""
+    out = []
+    for device_loop in (True, False):
+        IO = mgio.MgIO(text=_input(name, prec))
+        top = mgio.iomg_read(IO, dtype=DT[prec])
+        s = cycle.Solver(top, device_loop=device_loop)
+        try:
+            s.mg_gs_cds(mgio.read_method(IO))
+            out.append(([l.itt for l in top.levels()], s.history_array(), top.dev.download()))
+        finally:
+            s.close()
+    (p0, h0, W0), (p1, h1, W1) = out
+    assert p0 == p1 and len(h0) == len(h1)
+    for f in ("layer", "kind", "itt", "tol", "sum", "err"):
+        assert np.array_equal(h0[f], h1[f]), f
+    assert bits_equal(W0, W1)
+
+
+def test_device_side_loop_stops_at_the_sweep_budget():
+    from multigrid_amd import lib
+    IO = mgio.MgIO(text=_input("solve_64_bu", "f64"))
+    top = mgio.iomg_read(IO, dtype=np.float64)
+    s = cycle.Solver(top, max_sweeps=30)
+    try:
+        with pytest.raises(Exception) as e:
+            s.mg_gs_cds(mgio.read_method(IO))
+        assert "more than 30 sweeps" in str(e.value)
+        assert s.total_sweeps == 30
+    finally:
+        s.close()
