@@ -70,6 +70,23 @@ int mgx_ctx_destroy(mgx_ctx *ctx);
 int mgx_ctx_sync(mgx_ctx *ctx);                                   /* [sync] */
 int mgx_ctx_set_kernel(mgx_ctx *ctx, int which);                   /* MGX_KERNEL_* */
 
+/* One cycle of gs_V (m_gs_CDS.F90:220-294: legs of sweeps, restrictions, prolongations, the set-ups inside them) holds
+ * no host decision, so it can be recorded once and replayed: between _begin and _end every call on the context's
+ * levels is recorded into a HIP graph instead of run (calls that wait for the device, copy to or from the host or
+ * allocate return MGX_ESTATE while recording: run the sequence once before recording it, so that tile lists and index
+ * tables exist).  _end hands out the graph and puts the levels' host-side state (which buffer is current, pending
+ * fills) back to where the recording began: nothing has run yet.  A graph remembers the state it was recorded from and
+ * the state it leaves: mgx_graph_launch enqueues one repetition on the context's stream if the levels are in the
+ * former (MGX_ESTATE otherwise: record another graph from this state, or call the routines one by one) and puts them
+ * into the latter.  A cycle that sweeps a level an odd number of passes alternates between two states and needs two
+ * graphs.  _end with out == NULL drops the recording.  No counterpart in the reference (its loop calls the routines
+ * one by one). */
+typedef struct mgx_graph mgx_graph;
+int mgx_ctx_capture_begin(mgx_ctx *ctx);
+int mgx_ctx_capture_end(mgx_ctx *ctx, mgx_graph **out);
+int mgx_graph_launch(mgx_graph *g);
+int mgx_graph_destroy(mgx_graph *g);
+
 /* Level storage — replaces grid_bring_back / grid_hold_back (t_mg.f90:590-612).
  * A level is allocated once and stays resident in HBM.  n = interior size.
  * The slab form describes planes [z0+1, z0+n3_local] of a global level of

@@ -31,6 +31,9 @@ def main(argv=None) -> int:
     IO = mgio.MgIO(path=filein)
     top = mgio.iomg_read(IO, dtype=precision)
     method = mgio.read_method(IO)
+    if method == cycle.CDS_W_CYCLE and any(float(g.sor) > cycle.RB_SOR_LIMIT for g in top.levels()):
+        print("warning: `method v-cycle` with sor > 1.7." + cycle.divergence_hint(max(float(g.sor) for g in top.levels())),
+              file=sys.stderr)
     solver = cycle.Solver(top, verbose=True)
     try:
         names = mgio.save_names(IO, "init-save")

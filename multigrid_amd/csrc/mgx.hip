@@ -41,6 +41,13 @@ static int fail(int code, const char *fmt, ...) {
     if (r_ != MGX_OK) return r_; \
   } while (0)
 
+// calls that wait for the device, copy to or from the host or allocate cannot be recorded into a graph
+#define NOT_WHILE_CAPTURING(ctx_, who)                                                              \
+  do {                                                                                             \
+    if ((ctx_) && (ctx_)->capturing)                                                               \
+      return fail(MGX_ESTATE, "%s: not while the context records a graph (mgx_ctx_capture_begin)", who); \
+  } while (0)
+
 extern "C" const char *mgx_last_error(void) { return g_err; }
 extern "C" const char *mgx_version(void) { return "mgx 0.1 (gfx950)"; }
 
@@ -60,6 +67,8 @@ static int mgx_pair_pass = -1;   // 0: never two sweeps per pass, 1: wherever th
 // ------------------------------------------------------------------------------------------------
 // objects
 
+struct MgxLevelState { int cur; bool shell_synced, defined, inner_pending, zero_pending; };
+
 struct mgx_ctx {
   int device = 0;
   hipStream_t stream = nullptr;
@@ -68,6 +77,9 @@ struct mgx_ctx {
   u64 *h_res = nullptr;        // pinned read-back buffer
   double *h_solve = nullptr;   // pinned read-back buffer of mgx_level_solve (state + one batch of history)
   hipStream_t aux = nullptr;   // side stream: box tiles of the fused sweep run beside the others
+  bool capturing = false;      // between mgx_ctx_capture_begin and _end: calls are recorded, not run
+  std::vector<struct mgx_level *> levels;   // the levels of this context (their host-side state is checked around a capture)
+  std::vector<struct MgxLevelState> snapshot;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
 };
 
@@ -114,6 +126,14 @@ struct MgxTransferPlan {
 };
 
 static inline mgx_ctx *C(mgx_level *lv) { return lv->ctx; }
+
+static MgxLevelState level_state(const mgx_level *lv) {
+  return MgxLevelState{lv->cur, lv->shell_synced, lv->defined, lv->inner_pending, lv->zero_pending};
+}
+static void set_level_state(mgx_level *lv, const MgxLevelState &s) {
+  lv->cur = s.cur; lv->shell_synced = s.shell_synced; lv->defined = s.defined; lv->inner_pending = s.inner_pending;
+  lv->zero_pending = s.zero_pending;
+}
 
 template <typename T>
 static MgxSweepParams<T> make_params(const mgx_level *lv) {
@@ -198,8 +218,101 @@ extern "C" int mgx_ctx_destroy(mgx_ctx *ctx) {
 
 extern "C" int mgx_ctx_sync(mgx_ctx *ctx) {
   if (!ctx) return fail(MGX_EINVAL, "mgx_ctx_sync: ctx is NULL");
+  NOT_WHILE_CAPTURING(ctx, "mgx_ctx_sync");
   TRY(set_device(ctx));
   HIP_TRY(hipStreamSynchronize(ctx->stream));
+  return MGX_OK;
+}
+
+// ---- recording a sequence of calls into a HIP graph ----
+// Everything the library enqueues between _begin and _end (sweeps, transfers, set-ups, fills) is recorded on the
+// context's stream instead of run.  The host-side state of every level (which buffer is current, pending fills, ...)
+// advances while recording as it would while running, and the recorded kernels carry the buffers of that state: a
+// graph therefore remembers the state it was recorded from and the state it leaves, may only be launched from the
+// former (MGX_ESTATE otherwise) and puts the levels into the latter.  One V-cycle of gs_V (m_gs_CDS.F90:220-294)
+// returns to its starting state when every level takes an even number of passes per cycle, and alternates between
+// two states otherwise: the host keeps one graph per starting state.
+struct mgx_graph {
+  mgx_ctx *ctx = nullptr;
+  hipGraph_t graph = nullptr;
+  hipGraphExec_t exec = nullptr;
+  std::vector<mgx_level *> levels;
+  std::vector<MgxLevelState> from, to;
+};
+
+static MgxLevelState level_state(const mgx_level *lv);
+static void set_level_state(mgx_level *lv, const MgxLevelState &s);
+static bool same_state(const MgxLevelState &a, const MgxLevelState &b) {
+  return a.cur == b.cur && a.shell_synced == b.shell_synced && a.defined == b.defined &&
+         a.inner_pending == b.inner_pending && a.zero_pending == b.zero_pending;
+}
+
+extern "C" int mgx_ctx_capture_begin(mgx_ctx *ctx) {
+  if (!ctx) return fail(MGX_EINVAL, "mgx_ctx_capture_begin: ctx is NULL");
+  if (ctx->capturing) return fail(MGX_ESTATE, "mgx_ctx_capture_begin: already recording");
+  TRY(set_device(ctx));
+  ctx->snapshot.clear();
+  for (const mgx_level *lv : ctx->levels) ctx->snapshot.push_back(level_state(lv));
+  HIP_TRY(hipStreamBeginCapture(ctx->stream, hipStreamCaptureModeRelaxed));
+  ctx->capturing = true;
+  return MGX_OK;
+}
+
+extern "C" int mgx_ctx_capture_end(mgx_ctx *ctx, mgx_graph **out) {
+  if (!ctx) return fail(MGX_EINVAL, "mgx_ctx_capture_end: ctx is NULL");
+  if (!ctx->capturing) return fail(MGX_ESTATE, "mgx_ctx_capture_end: not recording");
+  TRY(set_device(ctx));
+  ctx->capturing = false;
+  hipGraph_t graph = nullptr;
+  hipError_t e = hipStreamEndCapture(ctx->stream, &graph);
+  const bool levels_same = ctx->snapshot.size() == ctx->levels.size();
+  std::vector<MgxLevelState> to;
+  for (const mgx_level *lv : ctx->levels) to.push_back(level_state(lv));
+  // nothing of the recording has run: put the levels back where the device still is
+  for (size_t i = 0; i < ctx->levels.size() && i < ctx->snapshot.size(); ++i) set_level_state(ctx->levels[i], ctx->snapshot[i]);
+  if (e != hipSuccess || !graph || !levels_same || !out) {
+    if (graph) (void)hipGraphDestroy(graph);
+    if (e != hipSuccess) return fail(MGX_EHIP, "mgx_ctx_capture_end: hipStreamEndCapture: %s", hipGetErrorString(e));
+    if (!out) return MGX_OK;                     // dropped on purpose
+    return fail(MGX_ESTATE, "mgx_ctx_capture_end: levels were created or destroyed while recording");
+  }
+  mgx_graph *g = new mgx_graph();
+  g->ctx = ctx;
+  g->graph = graph;
+  g->levels = ctx->levels;
+  g->from = ctx->snapshot;
+  g->to = to;
+  e = hipGraphInstantiate(&g->exec, graph, nullptr, nullptr, 0);
+  if (e != hipSuccess) {
+    (void)hipGraphDestroy(graph);
+    delete g;
+    return fail(MGX_EHIP, "mgx_ctx_capture_end: hipGraphInstantiate: %s", hipGetErrorString(e));
+  }
+  *out = g;
+  return MGX_OK;
+}
+
+extern "C" int mgx_graph_launch(mgx_graph *g) {
+  if (!g || !g->exec) return fail(MGX_EINVAL, "mgx_graph_launch: NULL graph");
+  mgx_ctx *ctx = g->ctx;
+  if (ctx->capturing) return fail(MGX_ESTATE, "mgx_graph_launch: the context is recording");
+  if (ctx->levels != g->levels) return fail(MGX_ESTATE, "mgx_graph_launch: the context's levels are not those of the recording");
+  for (size_t i = 0; i < g->levels.size(); ++i)
+    if (!same_state(level_state(g->levels[i]), g->from[i]))
+      return fail(MGX_ESTATE, "mgx_graph_launch: level %d is not in the state the graph was recorded from", g->levels[i]->layer);
+  TRY(set_device(ctx));
+  HIP_TRY(hipGraphLaunch(g->exec, ctx->stream));
+  for (size_t i = 0; i < g->levels.size(); ++i) set_level_state(g->levels[i], g->to[i]);
+  return MGX_OK;
+}
+
+extern "C" int mgx_graph_destroy(mgx_graph *g) {
+  if (!g) return MGX_OK;
+  (void)hipSetDevice(g->ctx->device);
+  (void)hipStreamSynchronize(g->ctx->stream);
+  if (g->exec) (void)hipGraphExecDestroy(g->exec);
+  if (g->graph) (void)hipGraphDestroy(g->graph);
+  delete g;
   return MGX_OK;
 }
 
@@ -216,6 +329,7 @@ extern "C" int mgx_ctx_set_kernel(mgx_ctx *ctx, int which) {
 extern "C" int mgx_level_create_slab(mgx_ctx *ctx, int layer, const int32_t n[3], int32_t z0, int32_t n3_local,
                                      int elem_bytes, mgx_level **out) {
   if (!ctx || !n || !out) return fail(MGX_EINVAL, "mgx_level_create: NULL argument");
+  NOT_WHILE_CAPTURING(ctx, "mgx_level_create");
   if (elem_bytes != 4 && elem_bytes != 8) return fail(MGX_EINVAL, "mgx_level_create: elem_bytes %d (want 4 or 8)", elem_bytes);
   if (n[0] < 1 || n[1] < 1 || n[2] < 1) return fail(MGX_EINVAL, "mgx_level_create: n = %d %d %d", n[0], n[1], n[2]);
   if (z0 < 0 || n3_local < 1 || z0 + n3_local > n[2])
@@ -256,6 +370,7 @@ extern "C" int mgx_level_create_slab(mgx_ctx *ctx, int layer, const int32_t n[3]
   }
   lv->shell_synced = true;
   lv->defined = true;
+  ctx->levels.push_back(lv);
   *out = lv;
   return MGX_OK;
 }
@@ -267,6 +382,8 @@ extern "C" int mgx_level_create(mgx_ctx *ctx, int layer, const int32_t n[3], int
 
 extern "C" int mgx_level_destroy(mgx_level *lv) {
   if (!lv) return MGX_OK;
+  if (lv->ctx->capturing) return fail(MGX_ESTATE, "mgx_level_destroy: not while the context records a graph");
+  lv->ctx->levels.erase(std::remove(lv->ctx->levels.begin(), lv->ctx->levels.end(), lv), lv->ctx->levels.end());
   (void)hipSetDevice(lv->ctx->device);
   (void)hipStreamSynchronize(lv->ctx->stream);
   (void)hipFree(lv->buf[0]);
@@ -318,6 +435,7 @@ extern "C" int mgx_level_set_params(mgx_level *lv, double sor, const double a[3]
 extern "C" int mgx_level_set_boxes(mgx_level *lv, int32_t nbox, const int32_t *place, const double *val,
                                    const double *rho, const int32_t *constant) {
   if (!lv) return fail(MGX_EINVAL, "mgx_level_set_boxes: NULL level");
+  NOT_WHILE_CAPTURING(C(lv), "mgx_level_set_boxes");
   if (nbox < 0 || (nbox > 0 && (!place || !val || !rho || !constant)))
     return fail(MGX_EINVAL, "mgx_level_set_boxes: nbox = %d with NULL table", nbox);
   TRY(set_device(C(lv)));
@@ -479,6 +597,7 @@ static int do_sweeps(mgx_level *lv, int nsweeps, int reduce) {
       const int red = (s + 2 == nsweeps) ? reduce : 0;
       if (red) TRY(reset_result(lv));
       TRY(sync_shell<T>(lv));
+      if (!lv->plan2.valid) NOT_WHILE_CAPTURING(C(lv), "mgx_level_sweep (first pair pass of a level builds its tile lists)");
       if (!lv->plan2.valid && mgx_fused_make_plan(lv->plan2, g, lv->boxes, C(lv)->stream, 2) != 0)
         return fail(MGX_EHIP, "mgx_level_sweep: could not build the tile lists of the two-sweep kernel");
       if (mgx_tb2_launch(lv->plan2, (const T *)lv->buf[lv->cur], (T *)lv->buf[1 - lv->cur], g,
@@ -494,6 +613,7 @@ static int do_sweeps(mgx_level *lv, int nsweeps, int reduce) {
     if (red) TRY(reset_result(lv));
     if (which == MGX_KERNEL_FUSED) {
       TRY(sync_shell<T>(lv));
+      if (!lv->plan.valid) NOT_WHILE_CAPTURING(C(lv), "mgx_level_sweep (first sweep of a level builds its tile lists)");
       if (!lv->plan.valid && mgx_fused_make_plan(lv->plan, g, lv->boxes, C(lv)->stream) != 0)
         return fail(MGX_EHIP, "mgx_level_sweep: could not build the tile lists of the fused kernel");
       if (mgx_fused_launch(lv->plan, 0, (const T *)lv->buf[lv->cur], (T *)lv->buf[1 - lv->cur], g, make_params<T>(lv),
@@ -542,6 +662,7 @@ static int do_sweep_part(mgx_level *lv, int part, int reduce) {
     if (lv->inner_pending) return fail(MGX_ESTATE, "mgx_level_sweep_part: the inner part of the previous sweep is still due");
     if (reduce) TRY(reset_result(lv));
     TRY(sync_shell<T>(lv));
+    if (!lv->plan.valid) NOT_WHILE_CAPTURING(C(lv), "mgx_level_sweep_part (first sweep of a level builds its tile lists)");
     if (!lv->plan.valid && mgx_fused_make_plan(lv->plan, g, lv->boxes, C(lv)->stream) != 0)
       return fail(MGX_EHIP, "mgx_level_sweep_part: could not build the tile lists of the fused kernel");
     if (mgx_fused_launch(lv->plan, 1, (const T *)lv->buf[lv->cur], (T *)lv->buf[1 - lv->cur], g, make_params<T>(lv),
@@ -644,6 +765,7 @@ extern "C" int mgx_level_solve(mgx_level *lv, double tol_level, int64_t count_no
   if (!lv->params_set) return fail(MGX_ESTATE, "mgx_level_solve: mgx_level_set_params not called");
   if (!lv->defined) return fail(MGX_ESTATE, "mgx_level_solve: level %d was released", lv->layer);
   if (lv->inner_pending) return fail(MGX_ESTATE, "mgx_level_solve: the inner part of a split sweep is still due");
+  NOT_WHILE_CAPTURING(C(lv), "mgx_level_solve");
   if (lv->g.n3 != lv->g.n3g) return fail(MGX_ESTATE, "mgx_level_solve: a slab needs a halo exchange between sweeps: loop on the host");
   const bool ok = lv->elem == 4 ? mgx_fused_supported<float>(lv->g, lv->nbox) : mgx_fused_supported<double>(lv->g, lv->nbox);
   if (!ok || C(lv)->kernel == MGX_KERNEL_TWO_PASS)
@@ -698,6 +820,7 @@ static int fetch_result(mgx_level *lv, double *err, double *sum, uint64_t limbs_
 
 extern "C" int mgx_level_result(mgx_level *lv, double *err_sq_max, double *abs_sum, uint64_t sum_limbs[2]) {
   if (!lv) return fail(MGX_EINVAL, "mgx_level_result: NULL level");
+  NOT_WHILE_CAPTURING(C(lv), "mgx_level_result");
   TRY(set_device(C(lv)));
   return fetch_result(lv, err_sq_max, abs_sum, sum_limbs);
 }
@@ -715,6 +838,7 @@ static int launch_abs_sum(mgx_level *lv) {
 
 extern "C" int mgx_level_abs_sum_limbs(mgx_level *lv, uint64_t limbs[2]) {
   if (!lv || !limbs) return fail(MGX_EINVAL, "mgx_level_abs_sum_limbs: NULL argument");
+  NOT_WHILE_CAPTURING(C(lv), "mgx_level_abs_sum");
   if (!lv->defined) return fail(MGX_ESTATE, "mgx_level_abs_sum: level %d was released", lv->layer);
   TRY(set_device(C(lv)));
   TRY(materialize(lv));
@@ -881,6 +1005,7 @@ static int transfer_plan(const char *who, bool restrict_, mgx_level *src, mgx_le
       *out = t;
       return MGX_OK;
     }
+  NOT_WHILE_CAPTURING(C(dst), who);      // the first transfer between two levels builds and uploads its index tables
   // forward maps destination index -> source index, exactly as the reference's loops run
   std::vector<int> mx(gd.n1 + 2, 0), my(gd.n2 + 2, 0), mz(gd.n3g + 2, 0);
   if (restrict_) {                        // dst = child, src = parent
@@ -983,7 +1108,10 @@ extern "C" int mgx_restrict(mgx_level *parent, mgx_level *child, int method) {
   MgxTransferPlan *t = nullptr;
   TRY(transfer_plan("mgx_restrict", true, parent, child, method, &t));
   TRY(materialize(parent));
-  TRY(materialize(child));            // the full operator can leave child cells unwritten (odd sizes): they stay zero
+  // the full operator can leave child cells unwritten (odd sizes): they stay zero.  Between exactly halved undivided
+  // levels every interior cell is written and grid_setup then writes every ghost: a pending zero fill is void.
+  if (t->halved && child->g.n3 == child->g.n3g) child->zero_pending = false;
+  else TRY(materialize(child));
   const bool half = method == MGX_INTERP_HALF;
   TRY(child->elem == 4 ? launch_restrict<float>(half, parent, child, t) : launch_restrict<double>(half, parent, child, t));
   child->defined = true;
@@ -1029,6 +1157,7 @@ static int copy_field(mgx_level *lv, void *host, bool to_device) {
 
 extern "C" int mgx_level_upload(mgx_level *lv, const void *host) {
   if (!lv || !host) return fail(MGX_EINVAL, "mgx_level_upload: NULL argument");
+  NOT_WHILE_CAPTURING(C(lv), "mgx_level_upload");
   TRY(set_device(C(lv)));
   TRY(copy_field(lv, const_cast<void *>(host), true));
   lv->shell_synced = false;
@@ -1038,6 +1167,7 @@ extern "C" int mgx_level_upload(mgx_level *lv, const void *host) {
 
 extern "C" int mgx_level_download(mgx_level *lv, void *host) {
   if (!lv || !host) return fail(MGX_EINVAL, "mgx_level_download: NULL argument");
+  NOT_WHILE_CAPTURING(C(lv), "mgx_level_download");
   if (!lv->defined) return fail(MGX_ESTATE, "mgx_level_download: level %d was released", lv->layer);
   if (lv->inner_pending) return fail(MGX_ESTATE, "mgx_level_download: the inner part of a split sweep is still due on level %d", lv->layer);
   TRY(set_device(C(lv)));

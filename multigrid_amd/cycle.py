@@ -22,11 +22,25 @@ HIST_DTYPE = np.dtype([("layer", "i4"), ("kind", "i4"), ("itt", "i4"), ("pad_", 
                        ("tol", "f8"), ("sum", "f8"), ("err", "f8")])
 
 
+RB_SOR_LIMIT = 1.70   # largest over-relaxation at which the red-black v-cycle converged on every input tried
+
+
+def divergence_hint(sor: float) -> str:
+    """what to tell the user when a cycle blows up: the known stability limit of the red-black ordering"""
+    if sor <= RB_SOR_LIMIT:
+        return ""
+    return (f"  The level runs sor = {sor:g}.  In red-black order the reference's cycle (restriction and prolongation "
+            f"overwrite the levels, m_gs_CDS.F90:220-294) is stable only up to sor = 1.70 (periodic z) to 1.76 (Dirichlet "
+            f"z), whereas the reference's lexicographic sweep tolerates its parser default of 1.8 (m_mg_io.F90:87): "
+            f"put `sor 1.7` into the layers block.")
+
+
 class Solver:
     """Owns the device context and the resident levels of one hierarchy."""
 
     def __init__(self, top: G.MgGrid, device: int = 0, stream: Optional[int] = None, ctx: Optional[lib.Context] = None,
-                 verbose: bool = False, print_sums: bool = True, max_sweeps: int = 1 << 24, device_loop: bool = True):
+                 verbose: bool = False, print_sums: bool = True, max_sweeps: int = 1 << 24, device_loop: bool = True,
+                 use_graphs: bool = False):
         self.top = top
         self.ctx = ctx if ctx is not None else lib.Context(device, stream)
         self.own_ctx = ctx is None
@@ -34,6 +48,11 @@ class Solver:
         self.print_sums = print_sums       # evaluate the print-only sums of gs_V (m_gs_CDS.F90:238,245,269,275)
         self.max_sweeps = max_sweeps
         self.device_loop = device_loop     # grid_solve's loop through mgx_level_solve (test evaluated on the device)
+        # one cycle of gs_V recorded into a HIP graph and replayed (only the plain solver: a decomposed one
+        # communicates between the library calls).  Off by default: measured on MI355X / ROCm 7.2, replaying the ~60
+        # small launches of a cycle as a graph is no faster than enqueueing them one by one (128^3: 352 ms vs 341 ms)
+        self.use_graphs = use_graphs and type(self) is Solver
+        self._graphs = {}
         self.history: List[tuple] = []
         self.total_sweeps = 0
         self.t = top.dtype.type
@@ -91,7 +110,7 @@ class Solver:
     def tolerance(self, g) -> float:       # grid_tolerance, t_mg.f90:857-868
         return self.t(G.grid_tolerance(g))
 
-    def gs_steps(self, g, nsteps: int, want_sum: bool, fetch: bool = True):
+    def gs_steps(self, g, nsteps: int, want_sum: bool, fetch: bool = True, defer: bool = False):
         """`nsteps` × gs_step (m_gs_CDS.F90:296-315); returns the grid_sum after the last one if asked.
         grid%err = sqrt(max dV^2) of the last sweep.  With fetch=False the sweeps are only enqueued: the level keeps
         its result record until it is swept again, and grid%err is read from it when somebody asks (level_err)."""
@@ -102,16 +121,21 @@ class Solver:
         if self.total_sweeps > self.max_sweeps:
             raise G.MgStop(f"more than {self.max_sweeps} sweeps")
         g.dev.sweep(nsteps, lib.RED_ERR | (lib.RED_SUM if want_sum else 0))
-        if not (fetch or want_sum):
+        if not (fetch or want_sum) or defer:     # defer: the caller reads the result later (fetch_deferred)
             g.err_pending = True
             return None
+        return self.fetch_result(g, want_sum)
+
+    def fetch_result(self, g, want_sum: bool):
+        """read back the reductions of the level's last sweep: grid%err, and the grid_sum if asked"""
         e2, s, _ = g.dev.result()
         g.err = float(np.sqrt(self.t(e2)))
         g.err_pending = False
         if want_sum and s != s:
             # the reference would carry the overflowing sum through its `do while (tol > ...)` tests, which a NaN
             # ends as if converged (m_gs_CDS.F90:200-210); a diverging iteration is reported instead
-            raise G.MgStop(f"layer {g.layer}: |V| reached 2^20 or is not finite after {g.itt} sweeps: the iteration diverges")
+            raise G.MgStop(f"layer {g.layer}: |V| reached 2^20 or is not finite after {g.itt} sweeps: the iteration diverges."
+                           + divergence_hint(float(g.sor)))
         return self.t(s) if want_sum else None
 
     def level_err(self, g) -> float:
@@ -207,12 +231,13 @@ class Solver:
             self.record(grid, 0, t(tol_), t(sum_))
             self.say(f" itt {grid.itt - old_itt:6d} {float(t(tol_)):10.7f} {float(t(sum_) * nr):10.7f} {grid.err:10.7f}")
         if status == 2:
-            raise G.MgStop(f"layer {grid.layer}: |V| reached 2^20 or is not finite after {grid.itt} sweeps: the iteration diverges")
+            raise G.MgStop(f"layer {grid.layer}: |V| reached 2^20 or is not finite after {grid.itt} sweeps: the iteration diverges."
+                           + divergence_hint(float(grid.sor)))
         if status == 1:
             raise G.MgStop(f"more than {self.max_sweeps} sweeps")
         return True
 
-    def _leg(self, grid, want_sum: bool = False):
+    def _leg(self, grid, want_sum: bool = False, defer: bool = False):
         """steps × gs_step between two (print-only) sums: m_gs_CDS.F90:237-248 / :268-278.  Returns the grid_sum
         after the last step when asked (the caller's own grid_sum would read the same field)."""
         t = self.t
@@ -225,9 +250,64 @@ class Solver:
             self.say(f"      {'  ' * grid.layer}{grid.steps:6d} {float(tol):10.7f} {float(new_sum * nr):10.7f}")
             return new_sum
         # nobody reads the residual of an inner leg: its sweeps are enqueued without waiting for them
-        return self.gs_steps(grid, grid.steps, want_sum, fetch=False)
+        return self.gs_steps(grid, grid.steps, want_sum, fetch=False, defer=defer)
 
     def gs_V(self, pg, cg):
+        """m_gs_CDS.F90:220-294.  A cycle holds no host decision (when the print-only sums are off), so from its
+        second run on a pair of levels it is recorded once into a HIP graph and then replayed."""
+        if not (self.use_graphs and not self.print_sums and not self.verbose and hasattr(self.ctx, "capture_begin")):
+            return self._gs_V_calls(pg, cg)
+        levels = list(self.top.levels())
+        key = (pg.layer, cg.layer)
+        st = self._graphs.get(key)
+        if st is None:                       # first cycle of this pair: run it, so that every tile list and table exists
+            self._graphs[key] = {"graphs": [], "failed": False}
+            return self._gs_V_calls(pg, cg)
+        if st["failed"]:
+            return self._gs_V_calls(pg, cg)
+        for gr, delta, dtot in st["graphs"]:  # a graph replays from the buffer state it was recorded in
+            try:
+                gr.launch()
+            except lib.MgxError as e:
+                if e.code != -4:
+                    raise
+                continue
+            for g, d in zip(levels, delta):
+                g.itt += d
+            self.total_sweeps += dtot
+            break
+        else:
+            if len(st["graphs"]) >= 4:       # states keep coming that no recording starts from: call by call
+                st["failed"] = True
+                return self._gs_V_calls(pg, cg)
+            before, tot0 = [g.itt for g in levels], self.total_sweeps
+            try:
+                self.ctx.capture_begin()
+                try:
+                    self._gs_V_calls(pg, cg, defer=True)
+                except BaseException:
+                    self.ctx.capture_end(keep=False)
+                    raise
+                gr = self.ctx.capture_end()
+            except lib.MgxError as e:
+                if e.code != -4:             # MGX_ESTATE: this sequence cannot be recorded: call by call
+                    raise
+                for g, b in zip(levels, before):
+                    g.itt = b
+                self.total_sweeps = tot0
+                st["failed"] = True
+                return self._gs_V_calls(pg, cg)
+            delta = [g.itt - b for g, b in zip(levels, before)]
+            st["graphs"].append((gr, delta, self.total_sweeps - tot0))
+            gr.launch()                      # the counters of this cycle are in: it is the recording's first run
+        if self.total_sweeps > self.max_sweeps:
+            raise G.MgStop(f"more than {self.max_sweeps} sweeps")
+        for g, d in zip(levels, st["graphs"][0][1]):
+            if d:
+                g.err_pending = True
+        return self.fetch_result(pg, True) if pg.steps > 0 else None
+
+    def _gs_V_calls(self, pg, cg, defer: bool = False):
         """m_gs_CDS.F90:220-294.  Returns grid_sum(pg) as it stands when the cycle ends (the sum the caller
         evaluates next, m_gs_CDS.F90:149, comes out of the last sweep's own reduction), or None."""
         grid = pg
@@ -241,7 +321,7 @@ class Solver:
             grid = grid.child
         while True:
             last = grid.layer == pg.layer
-            s_end = self._leg(grid, want_sum=last)
+            s_end = self._leg(grid, want_sum=last, defer=defer)
             if last:
                 return s_end if grid.steps > 0 else None
             if grid.parent is not None:

@@ -138,6 +138,27 @@ module mgx_c
        integer(c_int64_t), intent(out) :: limbs(2)         ! bit patterns of the two uint64_t words
        integer(c_int) :: rc
      end function mgx_level_abs_sum_limbs
+     function mgx_ctx_capture_begin(ctx) bind(C, name="mgx_ctx_capture_begin") result(rc)
+       import :: c_int, c_ptr
+       type(c_ptr), value :: ctx
+       integer(c_int) :: rc
+     end function mgx_ctx_capture_begin
+     function mgx_ctx_capture_end(ctx, graph) bind(C, name="mgx_ctx_capture_end") result(rc)
+       import :: c_int, c_ptr
+       type(c_ptr), value :: ctx
+       type(c_ptr), intent(out) :: graph
+       integer(c_int) :: rc
+     end function mgx_ctx_capture_end
+     function mgx_graph_launch(graph) bind(C, name="mgx_graph_launch") result(rc)
+       import :: c_int, c_ptr
+       type(c_ptr), value :: graph
+       integer(c_int) :: rc
+     end function mgx_graph_launch
+     function mgx_graph_destroy(graph) bind(C, name="mgx_graph_destroy") result(rc)
+       import :: c_int, c_ptr
+       type(c_ptr), value :: graph
+       integer(c_int) :: rc
+     end function mgx_graph_destroy
      function mgx_level_solve(lv, tol_level, count_nonconst, old_sum, max_sweeps, hist_cap, hist, nsweeps, status) &
           bind(C, name="mgx_level_solve") result(rc)
        import :: c_int, c_int32_t, c_int64_t, c_double, c_ptr

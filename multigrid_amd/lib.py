@@ -23,6 +23,7 @@ PART_EDGE, PART_INNER = 1, 2
 
 SYMBOLS = [
     "mgx_last_error", "mgx_version", "mgx_ctx_create", "mgx_ctx_destroy", "mgx_ctx_sync", "mgx_ctx_set_kernel",
+    "mgx_ctx_capture_begin", "mgx_ctx_capture_end", "mgx_graph_launch", "mgx_graph_destroy",
     "mgx_level_create", "mgx_level_create_slab", "mgx_level_destroy", "mgx_level_bring_back", "mgx_level_release",
     "mgx_level_set_params", "mgx_level_set_boxes", "mgx_level_setup", "mgx_level_sweep", "mgx_level_sweep_part",
     "mgx_level_half_sweep",
@@ -65,6 +66,8 @@ def load():
     sig = {
         "mgx_ctx_create": [C.c_int, vp, C.POINTER(vp)],
         "mgx_ctx_destroy": [vp], "mgx_ctx_sync": [vp], "mgx_ctx_set_kernel": [vp, C.c_int],
+        "mgx_ctx_capture_begin": [vp], "mgx_ctx_capture_end": [vp, C.POINTER(vp)],
+        "mgx_graph_launch": [vp], "mgx_graph_destroy": [vp],
         "mgx_level_create": [vp, C.c_int, pi32, C.c_int, C.POINTER(vp)],
         "mgx_level_create_slab": [vp, C.c_int, pi32, i32, i32, C.c_int, C.POINTER(vp)],
         "mgx_level_destroy": [vp], "mgx_level_bring_back": [vp], "mgx_level_release": [vp],
@@ -100,6 +103,21 @@ def _ck(rc):
         raise MgxError(rc, load().mgx_last_error().decode())
 
 
+class Graph:
+    """a recorded sequence of library calls (mgx_graph)"""
+
+    def __init__(self, ctx, h):
+        self.ctx, self.h = ctx, h
+
+    def launch(self):
+        _ck(self.ctx.L.mgx_graph_launch(self.h))
+
+    def close(self):
+        if self.h:
+            self.ctx.L.mgx_graph_destroy(self.h)
+            self.h = None
+
+
 class Context:
     """one GPU + one stream (mgx_ctx).  `stream` = raw hipStream_t value (e.g. torch's cuda_stream) or None."""
 
@@ -111,6 +129,7 @@ class Context:
         self.device = device
         self.stream = int(stream) if stream else None   # None: the library enqueues on a stream of its own
         self._levels = []
+        self._graphs = []
 
     def set_kernel(self, which: int):
         _ck(self.L.mgx_ctx_set_kernel(self.h, which))
@@ -118,12 +137,30 @@ class Context:
     def sync(self):
         _ck(self.L.mgx_ctx_sync(self.h))
 
+    def capture_begin(self):
+        """record the calls that follow into a HIP graph instead of running them"""
+        _ck(self.L.mgx_ctx_capture_begin(self.h))
+
+    def capture_end(self, keep: bool = True) -> Optional["Graph"]:
+        """end the recording; the Graph (not yet run: launch it), or None when dropped (keep=False)"""
+        if not keep:
+            _ck(self.L.mgx_ctx_capture_end(self.h, None))
+            return None
+        g = C.c_void_p()
+        _ck(self.L.mgx_ctx_capture_end(self.h, C.byref(g)))
+        gr = Graph(self, g)
+        self._graphs.append(gr)
+        return gr
+
     def level(self, layer: int, n: Sequence[int], dtype, z0: int = 0, n3_local: Optional[int] = None) -> "DeviceLevel":
         lv = DeviceLevel(self, layer, n, dtype, z0, n3_local)
         self._levels.append(lv)
         return lv
 
     def close(self):
+        for gr in self._graphs:
+            gr.close()
+        self._graphs = []
         for lv in self._levels:
             lv.close()
         self._levels = []

@@ -65,10 +65,25 @@ def test_divergent_solve_is_reported():
     s = cycle.Solver(top)
     try:
         from multigrid_amd import grid as G
-        with pytest.raises((lib.MgxError, G.MgStop)):
+        with pytest.raises((lib.MgxError, G.MgStop)) as e:
             s.mg_gs_cds(method)
+        assert "sor 1.7" in str(e.value)              # the message names the limit of the ordering and the remedy
     finally:
         s.close()
+
+
+def test_mg_program_warns_at_the_parsers_default_sor(tmp_path, capsys):
+    """an input without a `sor` line gets the parser's default 1.8 (m_mg_io.F90:87): `python -m multigrid_amd` says up
+    front that the red-black v-cycle is not stable there, and stops with the same advice instead of iterating on"""
+    from multigrid_amd import __main__ as prog
+    text = str(load("solve_80_v_f64")["input"])
+    lines = [l for l in text.splitlines() if not l.strip().startswith("sor")]
+    f = tmp_path / "mg.input"
+    f.write_text("\n".join(lines) + "\n")
+    rc = prog.main(["--double", str(f)])
+    err = capsys.readouterr().err
+    assert rc == 1
+    assert "warning" in err and "sor 1.7" in err and "diverges" in err
 
 
 @pytest.mark.parametrize("name,prec", [("solve_64x48x80_v_half", "f32"), ("solve_80_v", "f64")])
@@ -127,3 +142,26 @@ def test_device_side_loop_stops_at_the_sweep_budget():
         assert s.total_sweeps == 30
     finally:
         s.close()
+
+
+@pytest.mark.parametrize("name,prec", [("solve_64x48x80_v_half", "f32"), ("solve_80_v", "f64")])
+def test_recorded_cycle_equals_call_by_call(name, prec):
+    """gs_V (m_gs_CDS.F90:220-294) recorded into a HIP graph and replayed against the same cycle call by call:
+    identical sweep counts, history and field; and the recording is in use"""
+    out = []
+    for use_graphs in (True, False):
+        IO = mgio.MgIO(text=_input(name, prec))
+        top = mgio.iomg_read(IO, dtype=DT[prec])
+        s = cycle.Solver(top, print_sums=False, use_graphs=use_graphs)
+        try:
+            s.mg_gs_cds(mgio.read_method(IO))
+            out.append(([l.itt for l in top.levels()], s.history_array(), top.dev.download(),
+                        [k for k, v in s._graphs.items() if v["graphs"]]))
+        finally:
+            s.close()
+    (p0, h0, W0, g0), (p1, h1, W1, g1) = out
+    assert g0 and not g1
+    assert p0 == p1 and len(h0) == len(h1)
+    for f in ("layer", "kind", "itt", "tol", "sum", "err"):
+        assert np.array_equal(h0[f], h1[f]), f
+    assert bits_equal(W0, W1)
