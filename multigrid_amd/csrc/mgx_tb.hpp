@@ -246,6 +246,9 @@ __device__ __forceinline__ void mgx_tb_body(const T *__restrict__ src, T *__rest
   // one step: U = unroll position (parity of k - k0)
   auto step = [&](auto Uc, const int k) {
     constexpr int U = decltype(Uc)::value;
+#ifdef MGX_TB_ABLATE_BITS
+    if (!(reduce & 128))
+#endif
     fetch(F[DF == 2 ? U : 0], k + 1 + DF);
     bool boxy = false;
     if (BOXES) {
@@ -309,7 +312,11 @@ __device__ __forceinline__ void mgx_tb_body(const T *__restrict__ src, T *__rest
           char *pb = reinterpret_cast<char *>(dst + pzl * (z + 1));
 #pragma unroll
           for (int j = 0; j < R; ++j)
+#ifdef MGX_TB_ABLATE_BITS
+            if (st[j] && !(reduce & 64)) {
+#else
             if (st[j]) {
+#endif
               typedef T nv2 __attribute__((ext_vector_type(2)));
               nv2 o_;
               o_.x = P[L + 1][j].x;
@@ -318,7 +325,7 @@ __device__ __forceinline__ void mgx_tb_body(const T *__restrict__ src, T *__rest
             }
         }
         if constexpr (S >= L - 1) {              // the last sweep of the pass carries the reductions
-          if (!HALO && reduce) {
+          if (!HALO && (reduce & 3)) {
             const bool zown = z >= zc0 && z <= zc1;
             double a_[R];
 #pragma unroll
@@ -346,9 +353,15 @@ __device__ __forceinline__ void mgx_tb_body(const T *__restrict__ src, T *__rest
 #pragma unroll
     for (int j = 0; j < R; ++j) {
       const int q = MGX_TBQ(U, j);
-      A(0, 1 - U, li[j]) = MGX_CMP(P[0][j], q);
+#ifdef MGX_TB_ABLATE_BITS
+      if (!(reduce & 256)) {
+#else
+      {
+#endif
+        A(0, 1 - U, li[j]) = MGX_CMP(P[0][j], q);
 #pragma unroll
-      for (int sgl = 0; sgl < L; ++sgl) A(sgl + 1, 1 - U, li[j]) = MGX_CMP(P[sgl + 1][j], q);
+        for (int sgl = 0; sgl < L; ++sgl) A(sgl + 1, 1 - U, li[j]) = MGX_CMP(P[sgl + 1][j], q);
+      }
       below[j] = MGX_CMP(P[L + 1][j], 1 - q);
     }
     MGX_TB_SYNC();
@@ -379,7 +392,7 @@ __device__ __forceinline__ void mgx_tb_body(const T *__restrict__ src, T *__rest
   }
 #undef MGX_TBQ
 #undef MGX_CMP
-  if (reduce) mgx_block_commit<NW + 1>((double)(err * err), slo, shi, ovf, reduce, res);
+  if (reduce & 3) mgx_block_commit<NW + 1>((double)(err * err), slo, shi, ovf, reduce & 3, res);
 }
 
 template <typename T, int NS, int TY, int BOXES, int NW, int DF>
