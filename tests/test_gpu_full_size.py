@@ -141,3 +141,66 @@ def test_two_kernels_and_two_slabs_agree(ctx, hierarchy):
         whole.close()
         for lv in slabs:
             lv.close()
+
+
+def test_full_extent_slabs_2048x2048x256(ctx):
+    """two z slabs of 2048 x 2048 x 256 cells (the slab an 8-GPU run of the 2048^3 periodic configuration gives every
+    rank; here of a 2048 x 2048 x 512 level so that the undivided level fits beside them), fused kernel, one slab in one
+    launch and one in edge + inner launches, against the undivided level swept by the two-pass kernel: same bits after
+    two sweeps, same reductions.  Exercises the in-plane offsets and tile lists at that extent."""
+    from bench import config5_input
+    from multigrid_amd import lib, mgio, slab
+    top = mgio.iomg_read(mgio.MgIO(text=config5_input((2048, 2048, 512))), dtype=np.float64)
+    assert [int(v) for v in top.n] == [2048, 2048, 512]
+    parts = [(0, 256), (256, 256)]
+    red = lib.RED_ERR | lib.RED_SUM
+    made = []
+    try:
+        ctx.set_kernel(lib.KERNEL_TWO_PASS)
+        whole = _device(ctx, top)
+        made.append(whole)
+        whole.bring_back()
+        whole.setup(True)
+        res = []
+        for _ in range(2):
+            whole.sweep(1, red)
+            res.append(whole.result())
+        ctx.set_kernel(0)
+        slabs = [_device(ctx, top, z0, k) for z0, k in parts]
+        made += slabs
+        lo, up = slabs
+        for lv in slabs:
+            lv.bring_back()
+            lv.setup(True)
+        ctx.sync()
+        # periodic C faces of the set-up (whole planes), then the halo planes of both sides
+        slab.device_plane_tensor(lo, 0, 1).copy_(slab.device_plane_tensor(up, up.n3_local, 1))
+        slab.device_plane_tensor(up, up.n3_local + 1, 1).copy_(slab.device_plane_tensor(lo, 1, 1))
+
+        def exchange():
+            ctx.sync()
+            slab.device_plane_tensor(up, -1, 2).copy_(slab.device_plane_tensor(lo, lo.n3_local - 1, 2))
+            slab.device_plane_tensor(lo, lo.n3_local + 1, 2).copy_(slab.device_plane_tensor(up, 1, 2))
+            torch.cuda.synchronize()
+
+        exchange()
+        for lv in slabs:
+            lv.halo_written()
+        for it in range(2):
+            lo.sweep(1, red)
+            up.sweep_part(lib.PART_EDGE, red)
+            up.sweep_part(lib.PART_INNER, red)
+            rs = [lv.result() for lv in slabs]
+            exchange()
+            assert max(r[0] for r in rs) == res[it][0]
+            assert sum(r[2] for r in rs) == res[it][2]
+        for lv, (z0, k) in zip(slabs, parts):
+            # rows of a plane are pitched: compare the ghosted extent, not the padding behind it
+            mine = slab.device_plane_tensor(lv, 1, k).view(torch.int64).view(k, 2050, -1)[:, :, :2050]
+            ref = slab.device_plane_tensor(whole, z0 + 1, k).view(torch.int64).view(k, 2050, -1)[:, :, :2050]
+            assert bool(torch.equal(mine, ref))
+        assert res[1][1] > 0.0
+    finally:
+        ctx.set_kernel(0)
+        for lv in made:
+            lv.close()
