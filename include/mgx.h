@@ -69,6 +69,9 @@ int mgx_ctx_create(int device, void *stream, mgx_ctx **out);
 int mgx_ctx_destroy(mgx_ctx *ctx);
 int mgx_ctx_sync(mgx_ctx *ctx);                                   /* [sync] */
 int mgx_ctx_set_kernel(mgx_ctx *ctx, int which);                   /* MGX_KERNEL_* */
+/* the device and the hipStream_t a context enqueues on (for hosts that order their own transfers or events against
+ * the library's kernels, e.g. the halo exchange of mgx_rccl.h); either pointer may be NULL */
+int mgx_ctx_info(mgx_ctx *ctx, int *device, void **stream);
 
 /* One cycle of gs_V (m_gs_CDS.F90:220-294: legs of sweeps, restrictions, prolongations, the set-ups inside them) holds
  * no host decision, so it can be recorded once and replayed: between _begin and _end every call on the context's
@@ -97,6 +100,7 @@ int mgx_level_create(mgx_ctx *ctx, int layer, const int32_t n[3], int elem_bytes
 int mgx_level_create_slab(mgx_ctx *ctx, int layer, const int32_t n_global[3], int32_t z0,
                           int32_t n3_local, int elem_bytes, mgx_level **out);
 int mgx_level_destroy(mgx_level *lv);
+int mgx_level_context(mgx_level *lv, mgx_ctx **ctx);             /* the context a level was created on */
 /* grid_bring_back: the reference leaves V uninitialised (t_mg.f90:608); here it is defined as zero */
 int mgx_level_bring_back(mgx_level *lv);
 /* grid_hold_back: keeps the storage (levels stay resident); marks the field undefined */

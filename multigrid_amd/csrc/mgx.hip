@@ -316,6 +316,19 @@ extern "C" int mgx_graph_destroy(mgx_graph *g) {
   return MGX_OK;
 }
 
+extern "C" int mgx_ctx_info(mgx_ctx *ctx, int *device, void **stream) {
+  if (!ctx) return fail(MGX_EINVAL, "mgx_ctx_info: NULL context");
+  if (device) *device = ctx->device;
+  if (stream) *stream = (void *)ctx->stream;
+  return MGX_OK;
+}
+
+extern "C" int mgx_level_context(mgx_level *lv, mgx_ctx **ctx) {
+  if (!lv || !ctx) return fail(MGX_EINVAL, "mgx_level_context: NULL argument");
+  *ctx = lv->ctx;
+  return MGX_OK;
+}
+
 extern "C" int mgx_ctx_set_kernel(mgx_ctx *ctx, int which) {
   if (!ctx) return fail(MGX_EINVAL, "mgx_ctx_set_kernel: ctx is NULL");
   if (which < MGX_KERNEL_AUTO || which > MGX_KERNEL_PAIR) return fail(MGX_EINVAL, "mgx_ctx_set_kernel: %d", which);

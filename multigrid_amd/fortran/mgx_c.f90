@@ -6,6 +6,7 @@ module mgx_c
   implicit none
   public
 
+  integer(c_int), parameter :: MGX_BC_PERIODIC = 1, MGX_BC_DIRICHLET = 2, MGX_BC_NEUMANN = 3   ! t_bc.f90:13-15
   integer(c_int), parameter :: MGX_RED_ERR = 1, MGX_RED_SUM = 2
   integer(c_int), parameter :: MGX_PART_EDGE = 1, MGX_PART_INNER = 2
   integer(c_int), parameter :: MGX_KERNEL_AUTO = 0, MGX_KERNEL_TWO_PASS = 1, MGX_KERNEL_FUSED = 2, MGX_KERNEL_PAIR = 3
@@ -39,6 +40,19 @@ module mgx_c
        integer(c_int), value :: which
        integer(c_int) :: rc
      end function mgx_ctx_set_kernel
+     function mgx_ctx_info(ctx, device, stream) bind(C, name="mgx_ctx_info") result(rc)
+       import :: c_int, c_ptr
+       type(c_ptr), value :: ctx
+       integer(c_int), intent(out) :: device
+       type(c_ptr), intent(out) :: stream
+       integer(c_int) :: rc
+     end function mgx_ctx_info
+     function mgx_level_context(lv, ctx) bind(C, name="mgx_level_context") result(rc)
+       import :: c_int, c_ptr
+       type(c_ptr), value :: lv
+       type(c_ptr), intent(out) :: ctx
+       integer(c_int) :: rc
+     end function mgx_level_context
      function mgx_level_create(ctx, layer, n, elem_bytes, lv) bind(C, name="mgx_level_create") result(rc)
        import :: c_int, c_int32_t, c_ptr
        type(c_ptr), value :: ctx

@@ -23,6 +23,7 @@ PART_EDGE, PART_INNER = 1, 2
 
 SYMBOLS = [
     "mgx_last_error", "mgx_version", "mgx_ctx_create", "mgx_ctx_destroy", "mgx_ctx_sync", "mgx_ctx_set_kernel",
+    "mgx_ctx_info", "mgx_level_context",
     "mgx_ctx_capture_begin", "mgx_ctx_capture_end", "mgx_graph_launch", "mgx_graph_destroy",
     "mgx_level_create", "mgx_level_create_slab", "mgx_level_destroy", "mgx_level_bring_back", "mgx_level_release",
     "mgx_level_set_params", "mgx_level_set_boxes", "mgx_level_setup", "mgx_level_sweep", "mgx_level_sweep_part",
@@ -66,6 +67,7 @@ def load():
     sig = {
         "mgx_ctx_create": [C.c_int, vp, C.POINTER(vp)],
         "mgx_ctx_destroy": [vp], "mgx_ctx_sync": [vp], "mgx_ctx_set_kernel": [vp, C.c_int],
+        "mgx_ctx_info": [vp, C.POINTER(C.c_int), C.POINTER(vp)], "mgx_level_context": [vp, C.POINTER(vp)],
         "mgx_ctx_capture_begin": [vp], "mgx_ctx_capture_end": [vp, C.POINTER(vp)],
         "mgx_graph_launch": [vp], "mgx_graph_destroy": [vp],
         "mgx_level_create": [vp, C.c_int, pi32, C.c_int, C.POINTER(vp)],
