@@ -205,6 +205,17 @@ int mgx_level_plane_ptr(mgx_level *lv, int32_t z, int32_t count, void **ptr, siz
 /* tell the library that planes outside 1..n3_local were rewritten behind its back */
 int mgx_level_halo_written(mgx_level *lv);
 
+/* The loop of grid_add_box over every cell of a level (t_mg.f90:359-395; called per box and level from
+ * m_mg_io.F90 and the tests, recursing over the children, :404-414): the centres of the cells (x, y, z), 0-based,
+ * dL(:,1)*x + dL(:,2)*y + dL(:,3)*z + grid%offset + half a cell diagonal, are tested against the box
+ * [llc, llc + sum(box_cell, DIM=2)] (or the mirrored box, :378-385) in double precision with the reference's
+ * association, on the device; place receives xmin,xmax,ymin,ymax,zmin,zmax of the cells inside (1-based; memory order
+ * of Fortran's place(2,3)) after the "at least one point" step (:392-395).  A box that holds no cell centre gets
+ * huge(0) in all six (it matches no cell).  dL and box_cell are 3 x 3, column major (dL(:,1) first); offset is
+ * grid%offset.  The level need not exist: only its size and geometry enter.  [sync] */
+int mgx_box_place(mgx_ctx *ctx, const int32_t n[3], const double dL[9], const double offset[3],
+                  const double llc[3], const double box_cell[9], int32_t place[6]);
+
 /* introspection for tests and benchmarks */
 int mgx_level_info(mgx_level *lv, int32_t n[3], int32_t *elem_bytes, int64_t *pitch_x,
                    int64_t *pitch_plane, int64_t *device_bytes);

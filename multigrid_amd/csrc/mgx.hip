@@ -81,6 +81,7 @@ struct mgx_ctx {
   std::vector<struct mgx_level *> levels;   // the levels of this context (their host-side state is checked around a capture)
   std::vector<struct MgxLevelState> snapshot;
   hipEvent_t ev_fork = nullptr, ev_join = nullptr;
+  int *d_place = nullptr;      // six words of mgx_box_place (allocated on first use)
 };
 
 struct mgx_level {
@@ -212,6 +213,7 @@ extern "C" int mgx_ctx_destroy(mgx_ctx *ctx) {
   if (ctx->own_stream) (void)hipStreamDestroy(ctx->stream);
   if (ctx->h_res) (void)hipHostFree(ctx->h_res);
   if (ctx->h_solve) (void)hipHostFree(ctx->h_solve);
+  if (ctx->d_place) (void)hipFree(ctx->d_place);
   delete ctx;
   return MGX_OK;
 }
@@ -221,6 +223,40 @@ extern "C" int mgx_ctx_sync(mgx_ctx *ctx) {
   NOT_WHILE_CAPTURING(ctx, "mgx_ctx_sync");
   TRY(set_device(ctx));
   HIP_TRY(hipStreamSynchronize(ctx->stream));
+  return MGX_OK;
+}
+
+// ---- grid_add_box: index range of a box (t_mg.f90:359-395) ----
+extern "C" int mgx_box_place(mgx_ctx *ctx, const int32_t n[3], const double dL[9], const double offset[3],
+                             const double llc[3], const double box_cell[9], int32_t place[6]) {
+  if (!ctx || !n || !dL || !offset || !llc || !box_cell || !place) return fail(MGX_EINVAL, "mgx_box_place: NULL argument");
+  NOT_WHILE_CAPTURING(ctx, "mgx_box_place");
+  if (n[0] < 1 || n[1] < 1 || n[2] < 1) return fail(MGX_EINVAL, "mgx_box_place: n = %d %d %d", n[0], n[1], n[2]);
+  TRY(set_device(ctx));
+  MgxPlaceArgs a;
+  for (int i = 0; i < 3; ++i) {
+    for (int j = 0; j < 3; ++j) a.d[j][i] = dL[i + 3 * j];
+    // offset = grid%offset + (dL(:,1)+dL(:,2)+dL(:,3))*.5 (t_mg.f90:359); urc = llc + sum(box_cell, DIM=2) (:360)
+    a.off[i] = offset[i] + ((dL[i] + dL[i + 3]) + dL[i + 6]) * 0.5;
+    a.llc[i] = llc[i];
+    a.urc[i] = llc[i] + ((box_cell[i] + box_cell[i + 3]) + box_cell[i + 6]);
+    a.n[i] = n[i];
+  }
+  if (!ctx->d_place) HIP_TRY(hipMalloc((void **)&ctx->d_place, 8 * sizeof(int)));
+  const int init[6] = {0x7fffffff, 0x7fffffff, 0x7fffffff, 0, 0, 0};
+  int got[6];
+  HIP_TRY(hipMemcpyAsync(ctx->d_place, init, sizeof init, hipMemcpyHostToDevice, ctx->stream));
+  const long long rows = (long long)n[1] * n[2];
+  const long long want = (rows + 3) / 4;
+  const unsigned blocks = (unsigned)std::min<long long>(want, 256LL * 64);
+  hipLaunchKernelGGL(k_box_place, dim3(blocks), dim3(256), 0, ctx->stream, a, rows, ctx->d_place);
+  HIP_TRY(hipGetLastError());
+  HIP_TRY(hipMemcpyAsync(got, ctx->d_place, sizeof got, hipMemcpyDeviceToHost, ctx->stream));
+  HIP_TRY(hipStreamSynchronize(ctx->stream));
+  for (int i = 0; i < 3; ++i) {
+    place[2 * i] = got[i];
+    place[2 * i + 1] = std::max(got[3 + i], got[i]);       // "ensure at least one point", t_mg.f90:392-395
+  }
   return MGX_OK;
 }
 

@@ -72,7 +72,7 @@ struct MgxBoxLds {           // per-block copy of what the box logic needs
 
 #define MGX_CODE_CONST 128u     // the cell lies in a constant box: val returns V itself (m_gs_CDS.F90:726-727)
 #define MGX_CODE_GENERAL 256u   // neighbours in two boxes with rho != 1, or in one without a table
-struct MgxCodes { unsigned c[3]; };   // per pair: low half = black cell of plane k, high half = red cell of plane k-1
+template <int R> struct MgxCodes { unsigned c[R]; };   // per pair: low half = black cell of plane k, high half = red cell of plane k-1
 
 // code of one cell from the sets of its own position and of its neighbours' positions
 __device__ inline unsigned mgx_cell_code(const unsigned X0, const unsigned Xm, const unsigned Xp, const uint4 ys,
@@ -91,18 +91,18 @@ __device__ inline unsigned mgx_cell_code(const unsigned X0, const unsigned Xm, c
   return (general ? MGX_CODE_GENERAL : (((R & tb1) ? 64u : 0u) | m)) | ((X0 & c00 & cmask) ? MGX_CODE_CONST : 0u);
 }
 
-// codes of the (up to three) pairs of a lane for one step: black cells on the plane with Z sets (zm, z0, zp) around
-// it, red cells one plane below (zmm, zm, z0).  qsel bit j = position of the cell in pair j.
-template <typename T>
-__device__ inline MgxCodes mgx_box_codes(const MgxBoxLds<T> *bl, const int pcs, const int r0, const int r1,
-                                               const int r2, const unsigned qsel, const unsigned zmm, const unsigned zm,
-                                               const unsigned z0, const unsigned zp, const unsigned cmask,
-                                               const unsigned rmask, const unsigned tb0, const unsigned tb1) {
-  MgxCodes out;
+// codes of the R pairs of a lane (staged rows rr[]) for one step: black cells on the plane with Z sets (zm, z0, zp)
+// around it, red cells one plane below (zmm, zm, z0).  qsel bit j = position of the cell in pair j.
+template <typename T, int R>
+__device__ inline MgxCodes<R> mgx_box_codes(const MgxBoxLds<T> *bl, const int pcs, const int (&rr)[R],
+                                            const unsigned qsel, const unsigned zmm, const unsigned zm,
+                                            const unsigned z0, const unsigned zp, const unsigned cmask,
+                                            const unsigned rmask, const unsigned tb0, const unsigned tb1) {
+  MgxCodes<R> out;
   const uint4 xs4 = bl->xq[pcs];
 #pragma unroll
-  for (int j = 0; j < 3; ++j) {
-    const uint4 ys = bl->yq[j == 0 ? r0 : j == 1 ? r1 : r2];
+  for (int j = 0; j < R; ++j) {
+    const uint4 ys = bl->yq[rr[j]];
     const bool q = ((qsel >> j) & 1u) != 0u;
     const unsigned X0 = q ? xs4.z : xs4.y, Xm = q ? xs4.y : xs4.x, Xp = q ? xs4.w : xs4.z;
     out.c[j] = mgx_cell_code(X0, Xm, Xp, ys, zm, z0, zp, cmask, rmask, tb0, tb1) |
@@ -167,6 +167,39 @@ __device__ inline T mgx_cell_from_code(const unsigned code, const T vc, const T 
   return p.s1 * vc + p.s2 * avg;
 }
 
+// store of a finished pair that this sweep does not read again.  MGX_ST_POLICY picks the cache policy bits of
+// the instruction (experiment builds): 0 plain, 1 nt (default), 2 sc1, 3 sc0 sc1, 4 sc1 nt
+#ifndef MGX_ST_POLICY
+#define MGX_ST_POLICY 1
+#endif
+#if MGX_ST_POLICY == 2
+#define MGX_ST_BITS " sc1"
+#elif MGX_ST_POLICY == 3
+#define MGX_ST_BITS " sc0 sc1"
+#elif MGX_ST_POLICY == 4
+#define MGX_ST_BITS " sc1 nt"
+#endif
+typedef double mgx_d2v __attribute__((ext_vector_type(2)));
+typedef float mgx_f2v __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ void mgx_stream_store(const mgx_d2v v, mgx_d2v *ptr) {
+#if MGX_ST_POLICY == 0
+  *ptr = v;
+#elif MGX_ST_POLICY == 1
+  __builtin_nontemporal_store(v, ptr);
+#else
+  asm volatile("global_store_dwordx4 %0, %1, off" MGX_ST_BITS : : "v"(ptr), "v"(v));
+#endif
+}
+__device__ __forceinline__ void mgx_stream_store(const mgx_f2v v, mgx_f2v *ptr) {
+#if MGX_ST_POLICY == 0
+  *ptr = v;
+#elif MGX_ST_POLICY == 1
+  __builtin_nontemporal_store(v, ptr);
+#else
+  asm volatile("global_store_dwordx2 %0, %1, off" MGX_ST_BITS : : "v"(ptr), "v"(v));
+#endif
+}
+
 // max(m, |d|) in one instruction (a NaN difference is ignored, as by `|d| > m ? |d| : m`)
 __device__ __forceinline__ double mgx_max_abs(double m, double d) { return __builtin_fmax(m, __builtin_fabs(d)); }
 __device__ __forceinline__ float mgx_max_abs(float m, float d) { return __builtin_fmaxf(m, __builtin_fabsf(d)); }
@@ -224,9 +257,8 @@ __device__ __forceinline__ void mgx_fused_body(const T *__restrict__ src, T *__r
   int li[R], fl[R];
   unsigned gob[R];                       // byte offset of the pair inside a plane
   bool st[R];
-  int rr[3] = {0, 0, 0};                 // staged row of pair j
+  int rr[R];                             // staged row of pair j
   int pcs = 0;                           // staged pair column (the same for every pair of a lane)
-  static_assert(R <= 3, "a lane keeps the box codes of at most three pairs");
 #pragma unroll
   for (int j = 0; j < R; ++j) {
     int r, pc;
@@ -320,10 +352,19 @@ __device__ __forceinline__ void mgx_fused_body(const T *__restrict__ src, T *__r
 #define MGX_RED(set, up, j) (MGX_Q(up, j) ? W[set][j].x : W[set][j].y)      /* even cell */
 #define MGX_SET_BLK(set, up, j, v) { if (MGX_Q(up, j)) W[set][j].y = (v); else W[set][j].x = (v); }
 #define MGX_SET_RED(set, up, j, v) { if (MGX_Q(up, j)) W[set][j].x = (v); else W[set][j].y = (v); }
+#ifndef MGX_LD_NT_MASK
+#define MGX_LD_NT_MASK 0
+#endif
 #define MGX_FETCH(z, set)                                                              \
   {                                                                                    \
     const char *pb_ = reinterpret_cast<const char *>(src + pzl * ((z) + 1));           \
-    _Pragma("unroll") for (int j = 0; j < R; ++j) W[set][j] = *reinterpret_cast<const V2 *>(pb_ + gob[j]); \
+    _Pragma("unroll") for (int j = 0; j < R; ++j) {                                    \
+      typedef T lv2_ __attribute__((ext_vector_type(2)));                               \
+      if (!HALO && ((MGX_LD_NT_MASK >> j) & 1)) {                                       \
+        const lv2_ t_ = __builtin_nontemporal_load(reinterpret_cast<const lv2_ *>(pb_ + gob[j])); \
+        W[set][j].x = t_.x; W[set][j].y = t_.y;                                         \
+      } else W[set][j] = *reinterpret_cast<const V2 *>(pb_ + gob[j]);                   \
+    }                                                                                  \
   }
 #define MGX_STAGE(slot, set, up)                                                       \
   {                                                                                    \
@@ -341,13 +382,13 @@ __device__ __forceinline__ void mgx_fused_body(const T *__restrict__ src, T *__r
   make_zsets(zc0 - 1 + g.z0, (zc0 - 1) & 1);
   MGX_SYNC();
   unsigned xyany = 0u;                   // boxes that can contain a cell of this lane's pairs, or a neighbour of one
-  unsigned codes[2][3];                  // box codes of the pairs, per step parity; valid for the Z sets in `key`
+  unsigned codes[2][R];                  // box codes of the pairs, per step parity; valid for the Z sets in `key`
   unsigned key[2][4];
   bool kvalid[2] = {false, false};
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
-    for (int j = 0; j < 3; ++j) codes[i][j] = 0u;
+    for (int j = 0; j < R; ++j) codes[i][j] = 0u;
 #pragma unroll
   for (int i = 0; i < 2; ++i)
 #pragma unroll
@@ -418,9 +459,9 @@ __device__ __forceinline__ void mgx_fused_body(const T *__restrict__ src, T *__r
             unsigned qsel = 0u;
 #pragma unroll
             for (int j = 0; j < R; ++j) qsel |= (unsigned)MGX_Q(u, j) << j;
-            const MgxCodes cd = mgx_box_codes<T>(bl, pcs, rr[0], rr[1], rr[2], qsel, zmm, zm, z0s, zp, cmask, rmask, tb0, tb1);
+            const MgxCodes<R> cd = mgx_box_codes<T, R>(bl, pcs, rr, qsel, zmm, zm, z0s, zp, cmask, rmask, tb0, tb1);
 #pragma unroll
-            for (int j = 0; j < 3; ++j) codes[u & 1][j] = cd.c[j];
+            for (int j = 0; j < R; ++j) codes[u & 1][j] = cd.c[j];
             key[u & 1][0] = zmm; key[u & 1][1] = zm; key[u & 1][2] = z0s; key[u & 1][3] = zp;
             kvalid[u & 1] = true;
           }
@@ -515,7 +556,7 @@ __device__ __forceinline__ void mgx_fused_body(const T *__restrict__ src, T *__r
             nv2 o_;
             o_.x = W[SM][j].x;
             o_.y = W[SM][j].y;
-            __builtin_nontemporal_store(o_, reinterpret_cast<nv2 *>(pb + gob[j]));
+            mgx_stream_store(o_, reinterpret_cast<nv2 *>(pb + gob[j]));
           }
         }
         if (reduce) {
@@ -632,6 +673,11 @@ static int mgx_fused_launch_t(const MgxFusedPlan &pl, int part, const T *src, T 
   switch (pl.ty * 100 + pl.nw) {
     case 1208: return mgx_fused_launch_cfg<T, 12, 8>(pl, part, src, dst, g, p, bx, nb, reduce, res, st, stop);
     case 2008: return mgx_fused_launch_cfg<T, 20, 8>(pl, part, src, dst, g, p, bx, nb, reduce, res, st, stop);
+#ifdef MGX_FUSED_TALL
+    case 2006: return mgx_fused_launch_cfg<T, 20, 6>(pl, part, src, dst, g, p, bx, nb, reduce, res, st, stop);
+    case 2606: return mgx_fused_launch_cfg<T, 26, 6>(pl, part, src, dst, g, p, bx, nb, reduce, res, st, stop);
+    case 3206: return mgx_fused_launch_cfg<T, 32, 6>(pl, part, src, dst, g, p, bx, nb, reduce, res, st, stop);
+#endif
     default: return mgx_fused_launch_cfg<T, 8, 4>(pl, part, src, dst, g, p, bx, nb, reduce, res, st, stop);
   }
 }

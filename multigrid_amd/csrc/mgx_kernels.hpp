@@ -755,3 +755,62 @@ __global__ __launch_bounds__(256) void k_transfer(const T *__restrict__ src, con
                        : mgx_stencil_prolong<T, HALF>(src, c, gs.px, gs.pz);
   dst[gd.idx(dx, dy, dz)] = v;
 }
+
+// ------------------------------------------------------------------------------------------------
+// grid_add_box's loop over all cells (t_mg.f90:363-390): which cell centres lie in the box [llc, urc] (either
+// orientation)?  The centre of cell (x, y, z), 0-based, is dL(:,1)*x + (dL(:,2)*y + (dL(:,3)*z + offset)) in double
+// precision with the reference's association; insert_point (:418-433) keeps the smallest and largest 1-based index per
+// axis, which does not depend on the visiting order: atomic min / max.  No memory is read.  One wave per (y, z) row
+// chunk: lane = x (stride 64); out = lo x, y, z (start: INT_MAX), hi x, y, z (start: 0).
+struct MgxPlaceArgs {
+  double d[3][3];      // d[j][i] = dL(i+1, j+1): column j of the cell matrix
+  double off[3], llc[3], urc[3];
+  int n[3];
+};
+
+static __global__ __launch_bounds__(256) void k_box_place(const MgxPlaceArgs a, const long long rows, int *__restrict__ out) {
+  const int lane = threadIdx.x & 63;
+  const long long wave = (long long)blockIdx.x * 4 + (threadIdx.x >> 6), nwave = (long long)gridDim.x * 4;
+  int lo[3] = {0x7fffffff, 0x7fffffff, 0x7fffffff}, hi[3] = {0, 0, 0};
+  for (long long r = wave; r < rows; r += nwave) {
+    const int y = (int)(r % a.n[1]), z = (int)(r / a.n[1]);
+    double dyz[3];
+#pragma unroll
+    for (int i = 0; i < 3; ++i) {
+      const double dz = a.d[2][i] * (double)z + a.off[i];      // t_mg.f90:365
+      dyz[i] = a.d[1][i] * (double)y + dz;                      // :367
+    }
+    bool any = false;
+    int xl = 0x7fffffff, xh = -1;
+    for (int x = lane; x < a.n[0]; x += 64) {
+      bool ge_llc = true, le_urc = true, ge_urc = true, le_llc = true;
+#pragma unroll
+      for (int i = 0; i < 3; ++i) {
+        const double c = a.d[0][i] * (double)x + dyz[i];        // :369
+        ge_llc = ge_llc && a.llc[i] <= c;
+        le_urc = le_urc && c <= a.urc[i];
+        ge_urc = ge_urc && a.urc[i] <= c;
+        le_llc = le_llc && c <= a.llc[i];
+      }
+      const bool in = ge_llc ? le_urc : (ge_urc && le_llc);     // :370-386
+      if (in) { any = true; xl = x < xl ? x : xl; xh = x > xh ? x : xh; }
+    }
+    if (any) {
+      lo[0] = min(lo[0], xl + 1); hi[0] = max(hi[0], xh + 1);
+      lo[1] = min(lo[1], y + 1);  hi[1] = max(hi[1], y + 1);
+      lo[2] = min(lo[2], z + 1);  hi[2] = max(hi[2], z + 1);
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < 3; ++i) {
+#pragma unroll
+    for (int m = 32; m >= 1; m >>= 1) {
+      lo[i] = min(lo[i], __shfl_xor(lo[i], m));
+      hi[i] = max(hi[i], __shfl_xor(hi[i], m));
+    }
+  }
+  if (lane == 0 && hi[0] > 0) {
+#pragma unroll
+    for (int i = 0; i < 3; ++i) { atomicMin(out + i, lo[i]); atomicMax(out + 3 + i, hi[i]); }
+  }
+}

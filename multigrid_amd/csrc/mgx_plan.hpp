@@ -43,7 +43,9 @@ static int mgx_fused_make_plan(MgxFusedPlan &pl, const MgxGeom &g, const std::ve
   if (g.n1 >= 96 && g.n2 >= 40) { pl.ty = 20; pl.nw = 8; } else { pl.ty = 8; pl.nw = 4; }
   if (mgx_fused_ty > 0) {
     const int want = mgx_fused_ty * 100 + mgx_fused_nw;
-    if (want == 804 || want == 1208 || want == 2008) { pl.ty = mgx_fused_ty; pl.nw = mgx_fused_nw; }
+    if (want == 804 || want == 1208 || want == 2008 || want == 2006 || want == 2606 || want == 3206) {
+      pl.ty = mgx_fused_ty; pl.nw = mgx_fused_nw;
+    }
   }
   if (ns == 2) { pl.ty = 22; pl.nw = 6; }      // the temporally blocked kernel: 128 x 22 tiles on 6 row waves
   pl.ntx = (g.n1 + 2 * TXP - 1) / (2 * TXP);

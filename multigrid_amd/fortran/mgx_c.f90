@@ -251,6 +251,14 @@ module mgx_c
        integer(c_int64_t), intent(out) :: pitch_x, pitch_plane, device_bytes
        integer(c_int) :: rc
      end function mgx_level_info
+     function mgx_box_place(ctx, n, dL, offset, llc, box_cell, place) bind(C, name="mgx_box_place") result(rc)
+       import :: c_int, c_int32_t, c_double, c_ptr
+       type(c_ptr), value :: ctx
+       integer(c_int32_t), intent(in) :: n(3)
+       real(c_double), intent(in) :: dL(3,3), offset(3), llc(3), box_cell(3,3)
+       integer(c_int32_t), intent(out) :: place(2,3)
+       integer(c_int) :: rc
+     end function mgx_box_place
      function mgx_strlen(s) bind(C, name="strlen") result(n)
        import :: c_ptr, c_size_t
        type(c_ptr), value :: s

@@ -7,6 +7,7 @@ bookkeeping lives in this module; every field operation goes to the HIP library.
 from __future__ import annotations
 
 import math
+import os
 from dataclasses import dataclass, field
 from typing import List, Optional, Sequence
 
@@ -209,6 +210,11 @@ def grid_BC(grid: MgGrid, BC: int, plane: Optional[int] = None) -> None:
         grid_BC(grid.child, BC, plane=plane)
 
 
+# how grid_add_box finds the cells of a box: "auto" = per-axis arithmetic on the host for orthogonal cells, the
+# device kernel for skewed ones; "device" = the device kernel always
+BOX_PLACEMENT = os.environ.get("MGX_BOX_PLACEMENT", "auto")
+
+
 def grid_add_box(grid: MgGrid, llc, box_cell, val: float, rho: float, constant: bool, recurse: Optional[bool] = None) -> None:
     """t_mg.f90:323-435: cell centres inside [llc, urc] (component-wise) define the index range."""
     if grid.N_box == 0:
@@ -236,9 +242,9 @@ def grid_add_box(grid: MgGrid, llc, box_cell, val: float, rho: float, constant: 
 
     n1, n2, n3 = (int(v) for v in grid.n)
     diagonal = all(grid.dL[i, j] == 0.0 for i in range(3) for j in range(3) if i != j)
-    if diagonal:
+    if diagonal and BOX_PLACEMENT != "device":
         # component i of a cell centre depends on the index along axis i only (adding the zero
-        # off-diagonal terms is exact), so both inclusion tests separate per axis
+        # off-diagonal terms is exact), so both inclusion tests separate per axis: O(n1 + n2 + n3) on the host
         cs = [grid.dL[i, i] * np.arange(n, dtype=np.float64) + offset[i] for i, n in enumerate((n1, n2, n3))]
         fwd = [llc[i] <= cs[i] for i in range(3)]
         inside = [np.nonzero(fwd[i] & (cs[i] <= urc[i]))[0] for i in range(3)]
@@ -256,19 +262,12 @@ def grid_add_box(grid: MgGrid, llc, box_cell, val: float, rho: float, constant: 
                             lo[i] = min(lo[i], v + 1)
                             hi[i] = max(hi[i], v + 1)
     else:
-        for z in range(n3):
-            dz = grid.dL[:, 2] * z + offset
-            yy = np.arange(n2, dtype=np.float64)
-            xx = np.arange(n1, dtype=np.float64)
-            dyz = grid.dL[:, 1][None, :] * yy[:, None] + dz[None, :]                # (n2,3)
-            xyz = grid.dL[:, 0][None, None, :] * xx[None, :, None] + dyz[:, None, :]  # (n2,n1,3)
-            fwd = np.all(llc <= xyz, axis=2)
-            ins = (fwd & np.all(xyz <= urc, axis=2)) | (~fwd & np.all(urc <= xyz, axis=2) & np.all(xyz <= llc, axis=2))
-            if ins.any():
-                ys, xs = np.nonzero(ins)
-                lo[0], hi[0] = min(lo[0], xs.min() + 1), max(hi[0], xs.max() + 1)
-                lo[1], hi[1] = min(lo[1], ys.min() + 1), max(hi[1], ys.max() + 1)
-                lo[2], hi[2] = min(lo[2], z + 1), max(hi[2], z + 1)
+        # skewed cells: the reference's loop over every cell (t_mg.f90:363-390), run on the GPU (mgx_box_place);
+        # there is no host form of it here
+        from . import lib
+        pl = lib.shared_context().box_place((n1, n2, n3), grid.dL, grid.offset, llc, box_cell)
+        lo[:] = pl[0::2]
+        hi[:] = np.where(pl[0::2] == HUGE_INT, 0, pl[1::2])
 
     hi = np.maximum(hi, lo)                  # "ensure at least one point", t_mg.f90:392-395
     box.place[:] = [lo[0], hi[0], lo[1], hi[1], lo[2], hi[2]]

@@ -32,6 +32,7 @@ SYMBOLS = [
     "mgx_level_abs_sum_noalloc", "mgx_level_solve",
     "mgx_limbs_to_double", "mgx_level_count_nonconst", "mgx_level_tolerance", "mgx_restrict", "mgx_prolong",
     "mgx_level_upload", "mgx_level_download", "mgx_level_plane_ptr", "mgx_level_halo_written", "mgx_level_info",
+    "mgx_box_place",
 ]
 
 
@@ -91,6 +92,7 @@ def load():
         "mgx_level_plane_ptr": [vp, i32, i32, C.POINTER(vp), C.POINTER(C.c_size_t)],
         "mgx_level_halo_written": [vp],
         "mgx_level_info": [vp, pi32, pi32, C.POINTER(i64), C.POINTER(i64), C.POINTER(i64)],
+        "mgx_box_place": [vp, pi32, pdbl, pdbl, pdbl, pdbl, pi32],
     }
     for name, args in sig.items():
         f = getattr(L, name)
@@ -98,6 +100,17 @@ def load():
         f.restype = C.c_int
     _lib = L
     return L
+
+
+_shared = {}
+
+
+def shared_context(device: int = 0) -> "Context":
+    """a context (own stream) kept for the life of the process, for host-side helpers that need the device before
+    any solver exists (box placement while an input file is read)"""
+    if device not in _shared:
+        _shared[device] = Context(device)
+    return _shared[device]
 
 
 def _ck(rc):
@@ -153,6 +166,20 @@ class Context:
         gr = Graph(self, g)
         self._graphs.append(gr)
         return gr
+
+    def box_place(self, n: Sequence[int], dL, offset, llc, box_cell) -> np.ndarray:
+        """grid_add_box's loop over the cells of a level (t_mg.f90:359-395) on the device: xmin,xmax,ymin,ymax,zmin,zmax.
+        dL and box_cell are 3 x 3 with the lattice vectors as columns (dL[:, 0] = dL(:,1))."""
+        n3 = (C.c_int32 * 3)(*[int(v) for v in n])
+        d = np.asfortranarray(np.asarray(dL, dtype=np.float64).reshape(3, 3)).ravel(order="F")
+        b = np.asfortranarray(np.asarray(box_cell, dtype=np.float64).reshape(3, 3)).ravel(order="F")
+        o = np.ascontiguousarray(offset, dtype=np.float64)
+        l = np.ascontiguousarray(llc, dtype=np.float64)
+        out = (C.c_int32 * 6)()
+        pd = C.POINTER(C.c_double)
+        _ck(self.L.mgx_box_place(self.h, n3, d.ctypes.data_as(pd), o.ctypes.data_as(pd), l.ctypes.data_as(pd),
+                                 b.ctypes.data_as(pd), out))
+        return np.array(list(out), dtype=np.int64)
 
     def level(self, layer: int, n: Sequence[int], dtype, z0: int = 0, n3_local: Optional[int] = None) -> "DeviceLevel":
         lv = DeviceLevel(self, layer, n, dtype, z0, n3_local)

@@ -14,6 +14,7 @@ What is replaced (the callee side of the boundary; the reference's callers stay 
                    grid_hold_back      + mgx_level_release
                    grid_sum            -> mgx_level_abs_sum
                    grid_non_constant_elem -> mgx_level_count_nonconst
+                   grid_add_box        its loop over all cells (t_mg.f90:363-390) -> mgx_box_place
   t_mg_interp.f90  grid_restriction    -> mgx_restrict (includes the child's grid_setup)
                    grid_prolongation   -> mgx_prolong (includes the parent's grid_setup)
   m_gs_CDS.F90     gs                  -> mgx_level_sweep + mgx_level_result
@@ -118,6 +119,17 @@ def patch_t_mg(src, double):
     call mgx_check(mgx_level_count_nonconst(grid%h, cnt))
     elem = int(cnt)
 """, r"^.*integer :: x,y,z,elem.*$")
+    # grid_add_box: the OpenMP loop over every cell becomes one library call; the rest of the routine (slot search,
+    # val/rho/constant, the "at least one point" step, the recursion over the children) stays the reference's text
+    m = re.search(r"^!\$OMP parallel do default\(shared\), private\(x,y,z,xyz,dyz,dz\)\n.*?^!\$OMP end parallel do\n", s, flags=re.M | re.S)
+    if not m or "insert_point(box%place,x,y,z)" not in m.group(0):
+        raise SystemExit("dropin_patch: the cell loop of grid_add_box not recognised")
+    s = s[:m.start()] + """    if ( .not. c_associated(mgx_the_ctx) ) call mgx_check(mgx_ctx_create(0_c_int, c_null_ptr, mgx_the_ctx))
+    call mgx_check(mgx_box_place(mgx_the_ctx, int(grid%n, c_int32_t), grid%dL, grid%offset, llc, box_cell, mgx_place))
+    box%place = mgx_place
+""" + s[m.end():]
+    k = s.index("    type(mg_box), pointer :: box\n", s.index("recursive subroutine grid_add_box"))
+    s = s[:k] + "    integer(c_int32_t) :: mgx_place(2,3)\n" + s[k:]
     return s
 
 

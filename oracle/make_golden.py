@@ -273,6 +273,62 @@ end box
 }
 
 
+# grid_add_box (t_mg.f90:323-435) on orthogonal and skewed cells: levels, cell matrices (lattice vectors as columns),
+# offsets and boxes (llc, box_cell) incl. boxes outside the cell, mirrored boxes (negative extents), points and lines
+def _boxplace_cases():
+    rng = np.random.default_rng(20240611)
+    cases = {}
+    ortho = np.diag([2.4, 1.5, 3.1])
+    skew = np.array([[2.4, 0.6, 0.3], [0.2, 1.5, -0.4], [0.1, 0.25, 3.1]])      # columns = lattice vectors
+    hexa = np.array([[3.0, -1.5, 0.0], [0.0, 2.598076211353316, 0.0], [0.0, 0.0, 4.0]])
+    for name, n, cell, off in (("ortho", (24, 15, 31), ortho, (0., 0., 0.)), ("skew", (24, 15, 31), skew, (0.1, -0.2, 0.05)),
+                               ("hexa", (30, 30, 16), hexa, (0., 0., 0.)), ("thin", (70, 3, 5), skew, (0., 0., 0.))):
+        boxes = []
+        ext = np.abs(cell).sum(axis=1)
+        lo = np.minimum(cell, 0).sum(axis=1) + np.array(off)
+        for _ in range(10):
+            llc = lo + rng.uniform(-0.1, 0.9, 3) * ext
+            bc = np.diag(rng.uniform(0.02, 0.6, 3) * ext)
+            boxes.append((llc, bc))
+        llc = lo + 0.8 * ext
+        boxes.append((llc, np.diag(-0.5 * ext)))                   # mirrored: urc below llc (t_mg.f90:378-385)
+        boxes.append((lo + 0.5 * ext, np.zeros((3, 3))))          # a point (grid_add_point, :437-448)
+        bl = np.zeros((3, 3)); bl[1, 1] = 0.4 * ext[1]
+        boxes.append((lo + 0.3 * ext, bl))                         # a line (grid_add_line, :450-463)
+        boxes.append((lo + 5.0 * ext, np.diag(0.1 * ext)))         # outside the cell
+        sk = np.array([[0.3, 0.1, 0.0], [0.0, 0.25, 0.05], [0.02, 0.0, 0.4]]) * ext[:, None]
+        boxes.append((lo + 0.2 * ext, sk))                         # skewed box_cell: only its row sums enter (:360)
+        boxes.append((lo - 0.01 * ext, np.diag(1.2 * ext)))        # the whole cell
+        cases[name] = (n, cell, np.array(off), boxes)
+    return cases
+
+
+def gen_boxplace():
+    out = {}
+    for name, (n, cell, off, boxes) in _boxplace_cases().items():
+        with tempfile.TemporaryDirectory() as td:
+            case = os.path.join(td, "case.txt")
+            with open(case, "w") as f:
+                f.write(f"{n[0]} {n[1]} {n[2]}\n")
+                f.write(" ".join(repr(float(v)) for v in cell.ravel(order="F")) + "\n")
+                f.write(" ".join(repr(float(v)) for v in off) + "\n")
+                f.write(f"{len(boxes)}\n")
+                for llc, bc in boxes:
+                    f.write(" ".join(repr(float(v)) for v in llc) + " " +
+                            " ".join(repr(float(v)) for v in bc.ravel(order="F")) + "\n")
+            txt = subprocess.check_output([os.path.join(REF, "ref_boxplace_f64"), case], env=ENV).decode()
+        place = np.array([[int(t) for t in line.split()] for line in txt.strip().splitlines()], dtype=np.int64)
+        assert place.shape == (len(boxes), 6)
+        out[f"{name}_n"] = np.array(n, np.int32)
+        out[f"{name}_cell"] = cell
+        out[f"{name}_offset"] = off
+        out[f"{name}_llc"] = np.array([b[0] for b in boxes])
+        out[f"{name}_box_cell"] = np.array([b[1] for b in boxes])
+        out[f"{name}_place"] = place
+        print(name, place.tolist())
+    np.savez_compressed(os.path.join(OUT, "box_place.npz"), **out)
+
+
 def read_vmg(path, dt):
     """Fortran sequential unformatted (4-byte markers): comment(200), n(3) i4, offset(3) f8, cell(3,3) f8,
     then n3 records of (n1+2)(n2+2) reals: V(0:n1+1,0:n2+1,z), z=1..n3  (m_mg_save.F90:231-267)"""
@@ -367,7 +423,8 @@ def gen_test6():
         pack_solve("test6", prec, text, *run_mg(prec, text), subsample=6)
 
 
-GROUPS = dict(sweeps=gen_sweeps, transfer=gen_transfer, setup=gen_setup, solves=gen_solves, test6=gen_test6)
+GROUPS = dict(sweeps=gen_sweeps, transfer=gen_transfer, setup=gen_setup, solves=gen_solves, test6=gen_test6,
+              boxplace=gen_boxplace)
 
 if __name__ == "__main__":
     os.makedirs(OUT, exist_ok=True)

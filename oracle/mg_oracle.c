@@ -52,6 +52,50 @@ int64_t orc_count_nonconst(const orc_level *L)
   return n;
 }
 
+/* grid_add_box, t_mg.f90:359-395: the index range of a box on a level of n cells.  dL and box_cell are 3 x 3 column
+ * major (dL(:,1) first), offset is grid%offset.  Literal triple loop over all cells with the reference's
+ * association of the cell-centre arithmetic; insert_point (:418-433) as written. */
+void orc_box_place(const int n[3], const double dL[9], const double offset[3], const double llc[3],
+                   const double box_cell[9], int place[6])
+{
+  double off[3], urc[3];
+  int lo[3], hi[3];
+  for (int i = 0; i < 3; ++i) {
+    off[i] = offset[i] + ((dL[i] + dL[i + 3]) + dL[i + 6]) * .5;        /* :359 */
+    urc[i] = llc[i] + ((box_cell[i] + box_cell[i + 3]) + box_cell[i + 6]); /* :360 */
+    lo[i] = 2147483647;                                                  /* huge(0), :356 */
+    hi[i] = 0;                                                           /* :357 */
+  }
+  for (int z = 0; z < n[2]; ++z) {
+    double dz[3], dyz[3], xyz[3];
+    for (int i = 0; i < 3; ++i) dz[i] = dL[6 + i] * z + off[i];          /* :365 */
+    for (int y = 0; y < n[1]; ++y) {
+      for (int i = 0; i < 3; ++i) dyz[i] = dL[3 + i] * y + dz[i];        /* :367 */
+      for (int x = 0; x < n[0]; ++x) {
+        for (int i = 0; i < 3; ++i) xyz[i] = dL[i] * x + dyz[i];         /* :369 */
+        int in = 0;
+        if (llc[0] <= xyz[0] && llc[1] <= xyz[1] && llc[2] <= xyz[2]) {  /* :370 */
+          in = xyz[0] <= urc[0] && xyz[1] <= urc[1] && xyz[2] <= urc[2]; /* :373 */
+        } else if (urc[0] <= xyz[0] && urc[1] <= xyz[1] && urc[2] <= xyz[2]) { /* :378 */
+          in = xyz[0] <= llc[0] && xyz[1] <= llc[1] && xyz[2] <= llc[2]; /* :381 */
+        }
+        if (in) {                                                        /* insert_point, :418-433 */
+          const int c[3] = {x, y, z};
+          for (int i = 0; i < 3; ++i) {
+            if (c[i] < lo[i]) lo[i] = c[i] + 1;
+            if (hi[i] <= c[i]) hi[i] = c[i] + 1;
+          }
+        }
+      }
+    }
+  }
+  for (int i = 0; i < 3; ++i) {
+    if (hi[i] < lo[i]) hi[i] = lo[i];                                    /* :392-395 */
+    place[2 * i] = lo[i];
+    place[2 * i + 1] = hi[i];
+  }
+}
+
 /* Exact |V| accumulation: acc += rne(absval * 2^72) (round to nearest, ties to
  * even) as a 128-bit integer (limbs[0] low, limbs[1] high).  Values >= 2^20 or
  * non-finite cannot be accumulated safely for 2^34 cells and raise *overflow. */

@@ -112,6 +112,9 @@ def lib():
             f.argtypes = [C.POINTER(_Level), C.c_int, C.c_int, C.c_int, C.c_int, p, C.POINTER(_Hist),
                           C.c_int64, C.POINTER(C.c_int64), C.c_int64]
             f.restype = C.c_int64
+        pd_, pi_ = C.POINTER(C.c_double), C.POINTER(C.c_int)
+        _lib.orc_box_place.argtypes = [pi_, pd_, pd_, pd_, pd_, pi_]
+        _lib.orc_box_place.restype = None
         _lib.orc_count_nonconst.argtypes = [C.POINTER(_Level)]
         _lib.orc_count_nonconst.restype = C.c_int64
     return _lib
@@ -198,6 +201,20 @@ def abs_sum_exact(L: Level, V: np.ndarray) -> Tuple[float, int]:
     limbs = (C.c_uint64 * 2)()
     s = getattr(lib(), f"orc_abs_sum_exact_{_sfx(V.dtype)}")(arr, _ptr(V), limbs)
     return s, (int(limbs[1]) << 64) | int(limbs[0])
+
+
+def box_place(n, dL, offset, llc, box_cell) -> np.ndarray:
+    """grid_add_box's loop over the cells (t_mg.f90:359-395): xmin,xmax,ymin,ymax,zmin,zmax (1-based).
+    dL and box_cell are 3 x 3 with the lattice vectors as columns."""
+    nn = (C.c_int * 3)(*[int(v) for v in n])
+    d = np.asarray(dL, dtype=np.float64).reshape(3, 3).ravel(order="F").copy()
+    b = np.asarray(box_cell, dtype=np.float64).reshape(3, 3).ravel(order="F").copy()
+    o = np.ascontiguousarray(offset, dtype=np.float64)
+    l = np.ascontiguousarray(llc, dtype=np.float64)
+    out = (C.c_int * 6)()
+    pd = C.POINTER(C.c_double)
+    lib().orc_box_place(nn, d.ctypes.data_as(pd), o.ctypes.data_as(pd), l.ctypes.data_as(pd), b.ctypes.data_as(pd), out)
+    return np.array(list(out), dtype=np.int64)
 
 
 def count_nonconst(L: Level) -> int:
