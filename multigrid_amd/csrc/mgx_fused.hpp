@@ -226,7 +226,12 @@ __device__ inline void mgx_exact_add_nb(u64 &lo, u64 &hi, double a, unsigned &ov
 // given P0 = parity of y + z of item 0 on the first plane: colour conversion becomes register naming and
 // the neighbour side, the flag tested and the packing of the stored pair become constants.  The halo wave
 // (HALO) takes the even staged rows as item 0 and the odd ones as item 1, so item j adds j to the parity.
-template <typename T, int TY, int BOXES, int NW, int P0, bool HALO>
+// FREE: a row wave of a box-free tile whose staged rows are all interior rows and whose 128 columns are all
+// interior columns.  Every cell such a wave holds is an interior cell, so the only reason left not to update one is
+// that it lies in the part of the grown ring a half-sweep does not need; what is computed there is read only by
+// cells that are not needed either (a half-sweep's region is the previous one's shrunk by one cell), never stored
+// and never counted.  Such waves update unconditionally: no flag tests, no selects.
+template <typename T, int TY, int BOXES, int NW, int P0, bool HALO, bool FREE = false>
 __device__ __forceinline__ void mgx_fused_body(const T *__restrict__ src, T *__restrict__ dst, const MgxGeom &g,
                                                const MgxSweepParams<T> &p, const MgxBox *__restrict__ bx, const int nb,
                                                const int tx0, const int ty0, const int zc0, const int zc1,
@@ -484,7 +489,7 @@ __device__ __forceinline__ void mgx_fused_body(const T *__restrict__ src, T *__r
 #pragma unroll
         for (int j = 0; j < R; ++j) {
           const int q = MGX_Q(u, j);
-          actv[j] = (fl[j] & (q ? MGX_F_BLK1 : MGX_F_BLK0)) != 0;
+          actv[j] = FREE || (fl[j] & (q ? MGX_F_BLK1 : MGX_F_BLK0)) != 0;
           const T vc = MGX_BLK(SC, u, j), partner = MGX_RED(SC, u, j);
           const T zlo = MGX_RED(SM, u + 1, j), zhi = MGX_RED(SN, u + 1, j);   // planes k-1 and k+1 (same parity as each other)
           T vv;
@@ -500,7 +505,7 @@ __device__ __forceinline__ void mgx_fused_body(const T *__restrict__ src, T *__r
 #endif
           }
           vold[j] = vc;
-          cnew[j] = actv[j] ? vv : vc;
+          cnew[j] = FREE ? vv : (actv[j] ? vv : vc);
           MGX_SET_BLK(SC, u, j, cnew[j])
         }
 #pragma unroll
@@ -534,7 +539,7 @@ __device__ __forceinline__ void mgx_fused_body(const T *__restrict__ src, T *__r
 #pragma unroll
         for (int j = 0; j < R; ++j) {
           const int q = MGX_Q(u, j);                        // position of the even cell in the pair on plane k-1
-          actv[j] = (fl[j] & (q ? MGX_F_RED1 : MGX_F_RED0)) != 0;
+          actv[j] = FREE ? rowin[j] : (fl[j] & (q ? MGX_F_RED1 : MGX_F_RED0)) != 0;
           const T vc = MGX_RED(SM, u + 1, j), partner = MGX_BLK(SM, u + 1, j);
           const T zhi = MGX_BLK(SC, u, j);                  // new black value of plane k
           T vv;
@@ -549,7 +554,7 @@ __device__ __forceinline__ void mgx_fused_body(const T *__restrict__ src, T *__r
 #endif
           }
           vold[j] = vc;
-          rnew[j] = actv[j] ? vv : vc;
+          rnew[j] = FREE ? vv : (actv[j] ? vv : vc);
           MGX_SET_RED(SM, u + 1, j, rnew[j])
           if (st[j]) {            // the finished pair, as it sits in memory; streamed past the caches, which the
             typedef T nv2 __attribute__((ext_vector_type(2)));   // halo rows of neighbouring tiles need more
@@ -561,7 +566,8 @@ __device__ __forceinline__ void mgx_fused_body(const T *__restrict__ src, T *__r
         }
         if (reduce) {
 #pragma unroll
-          for (int j = 0; j < R; ++j) err = mgx_max_abs(err, rnew[j] - vold[j]);   // 0 where nothing was updated
+          for (int j = 0; j < R; ++j)
+            if (!FREE || rowin[j]) err = mgx_max_abs(err, rnew[j] - vold[j]);   // not FREE: 0 where nothing was updated
           if (reduce & 2) MGX_SUM_R(rnew[j], actv[j])
         }
       }
@@ -605,9 +611,14 @@ __device__ __forceinline__ void mgx_fused_tile(const T *__restrict__ src, T *__r
   const int wave = threadIdx.x >> 6;
   const bool halo = wave == NW;
   const int p0 = (ty0 - 2 + (halo ? 0 : wave) + zc0 - 1 + g.z0) & 1;
+  // (see FREE above) staged rows ty0-2 .. ty0+TY+1 and columns tx0 .. tx0+127 all interior
+  const bool free_rows = BOXES == 0 && ty0 - 2 >= 1 && ty0 + TY + 1 <= g.n2 && tx0 + 2 * TXP - 1 <= g.n1;
   if (halo) {
     if (p0) mgx_fused_body<T, TY, BOXES, NW, 1, true>(src, dst, g, p, bx, nb, tx0, ty0, zc0, zc1, reduce, res, lds, bl);
     else mgx_fused_body<T, TY, BOXES, NW, 0, true>(src, dst, g, p, bx, nb, tx0, ty0, zc0, zc1, reduce, res, lds, bl);
+  } else if (BOXES == 0 && free_rows) {
+    if (p0) mgx_fused_body<T, TY, 0, NW, 1, false, true>(src, dst, g, p, bx, nb, tx0, ty0, zc0, zc1, reduce, res, lds, bl);
+    else mgx_fused_body<T, TY, 0, NW, 0, false, true>(src, dst, g, p, bx, nb, tx0, ty0, zc0, zc1, reduce, res, lds, bl);
   } else {
     if (p0) mgx_fused_body<T, TY, BOXES, NW, 1, false>(src, dst, g, p, bx, nb, tx0, ty0, zc0, zc1, reduce, res, lds, bl);
     else mgx_fused_body<T, TY, BOXES, NW, 0, false>(src, dst, g, p, bx, nb, tx0, ty0, zc0, zc1, reduce, res, lds, bl);

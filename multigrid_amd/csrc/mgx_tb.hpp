@@ -62,7 +62,10 @@ __device__ __forceinline__ double mgx_abs_if(const double v, const bool cond) {
   return __hiloint2double((int)h, __double2loint(v));
 }
 
-template <typename T, int NS, int TY, int BOXES, int NW, int DF, int P0, bool HALO>
+// FREE: row wave of a box-free tile whose staged rows and 128 columns are all interior (see mgx_fused_body): every
+// stage updates every cell of the wave unconditionally; what that computes outside the stage's region is read only
+// by cells outside the next stage's region, never stored and never counted.
+template <typename T, int NS, int TY, int BOXES, int NW, int DF, int P0, bool HALO, bool FREE = false>
 __device__ __forceinline__ void mgx_tb_body(const T *__restrict__ src, T *__restrict__ dst, const MgxGeom &g,
                                             const MgxSweepParams<T> &p, const MgxBox *__restrict__ bx, const int nb,
                                             const int tx0, const int ty0, const int zc0, const int zc1,
@@ -290,7 +293,7 @@ __device__ __forceinline__ void mgx_tb_body(const T *__restrict__ src, T *__rest
 #pragma unroll
         for (int j = 0; j < R; ++j) {
           const int q = MGX_TBQ(U, j);
-          actv[j] = (fl[j] & (1u << (2 * S + q))) != 0u;
+          actv[j] = FREE || (fl[j] & (1u << (2 * S + q))) != 0u;
           const T vc = MGX_CMP(P[S + 1][j], q), partner = MGX_CMP(P[S + 1][j], 1 - q);
           const T zhi = MGX_CMP(P[S][j], q);
           T zlo;
@@ -305,7 +308,7 @@ __device__ __forceinline__ void mgx_tb_body(const T *__restrict__ src, T *__rest
             vv = p.s1 * vc + p.s2 * mgx_avg_uniform<T>(partner, other[j], vym[j], vyp[j], zlo, zhi, p.w);
           }
           vold[j] = vc;
-          cnew[j] = actv[j] ? vv : vc;
+          cnew[j] = FREE ? vv : (actv[j] ? vv : vc);
           if (q) P[S + 1][j].y = cnew[j]; else P[S + 1][j].x = cnew[j];
         }
         if constexpr (S == L) {
@@ -333,7 +336,7 @@ __device__ __forceinline__ void mgx_tb_body(const T *__restrict__ src, T *__rest
               const int q = MGX_TBQ(U, j);
               const bool urow = zown && rowin[j];
               if (urow) err = mgx_max_abs(err, cnew[j] - vold[j]);   // 0 where nothing was updated
-              a_[j] = mgx_abs_if((double)cnew[j], urow && (fl[j] & (1u << (16 + q))) != 0u);
+              a_[j] = mgx_abs_if((double)cnew[j], urow && (FREE || (fl[j] & (1u << (16 + q))) != 0u));
             }
             if (reduce & 2) mgx_sum_items<R>(a_, fh, fl2, slo, shi, ovf);
           }
@@ -406,9 +409,14 @@ __device__ __forceinline__ void mgx_tb_tile(const T *__restrict__ src, T *__rest
   const bool halo = wave == NW;
   // position of the black cell (odd x + y + z; pairs start at odd x) of the wave's first item on the plane of the first step
   const int p0 = (ty0 - 2 * NS + (halo ? 0 : wave) + (zc0 - (2 * NS - 1)) + g.z0) & 1;
+  // (see FREE above) staged rows ty0-2NS .. ty0+TY-1+2NS and columns tx0 .. tx0+127 all interior
+  const bool free_rows = BOXES == 0 && ty0 - 2 * NS >= 1 && ty0 + TY - 1 + 2 * NS <= g.n2 && tx0 + 127 <= g.n1;
   if (halo) {
     if (p0) mgx_tb_body<T, NS, TY, BOXES, NW, DF, 1, true>(src, dst, g, p, bx, nb, tx0, ty0, zc0, zc1, reduce, res, lds, bl);
     else mgx_tb_body<T, NS, TY, BOXES, NW, DF, 0, true>(src, dst, g, p, bx, nb, tx0, ty0, zc0, zc1, reduce, res, lds, bl);
+  } else if (BOXES == 0 && free_rows) {
+    if (p0) mgx_tb_body<T, NS, TY, 0, NW, DF, 1, false, true>(src, dst, g, p, bx, nb, tx0, ty0, zc0, zc1, reduce, res, lds, bl);
+    else mgx_tb_body<T, NS, TY, 0, NW, DF, 0, false, true>(src, dst, g, p, bx, nb, tx0, ty0, zc0, zc1, reduce, res, lds, bl);
   } else {
     if (p0) mgx_tb_body<T, NS, TY, BOXES, NW, DF, 1, false>(src, dst, g, p, bx, nb, tx0, ty0, zc0, zc1, reduce, res, lds, bl);
     else mgx_tb_body<T, NS, TY, BOXES, NW, DF, 0, false>(src, dst, g, p, bx, nb, tx0, ty0, zc0, zc1, reduce, res, lds, bl);

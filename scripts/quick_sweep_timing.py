@@ -30,7 +30,10 @@ lv.result()
 for reps in (10, 30):
     ctx.sync()
     t0 = time.perf_counter()
-    if os.environ.get("PER_SWEEP"):
+    if os.environ.get("PAIR"):          # two sweeps per call (the form of gs_V's legs), reductions on the second
+        for _ in range(reps // 2):
+            lv.sweep(2, red)
+    elif os.environ.get("PER_SWEEP"):
         for _ in range(reps):
             lv.sweep(1, red)
     else:
