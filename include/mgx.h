@@ -110,7 +110,8 @@ int mgx_level_release(mgx_level *lv);
  * given as A0,A1,B0,B1,C0,C1 */
 int mgx_level_set_params(mgx_level *lv, double sor, const double a[3], const int32_t bc[6]);
 /* box table (t_mg.f90:46-47,62-72); replaces the per-cell scans of is_constant /
- * val_constant / val_rho (t_mg.f90:634-687) */
+ * val_constant / val_rho (t_mg.f90:634-687).  Limit without a counterpart in the reference: every box needs
+ * |val| < 2^19 (MGX_ELIMIT otherwise), because the exact convergence sum covers |V| < 2^20. */
 int mgx_level_set_boxes(mgx_level *lv, int32_t nbox, const int32_t *place /*[nbox][6]*/,
                         const double *val, const double *rho, const int32_t *constant);
 

@@ -67,7 +67,7 @@ static int mgx_pair_pass = -1;   // 0: never two sweeps per pass, 1: wherever th
 // ------------------------------------------------------------------------------------------------
 // objects
 
-struct MgxLevelState { int cur; bool shell_synced, defined, inner_pending, zero_pending; };
+struct MgxLevelState { int cur; bool shell_synced, defined, inner_pending, zero_pending, slots_dirty; };
 
 struct mgx_ctx {
   int device = 0;
@@ -105,7 +105,8 @@ struct mgx_level {
   MgxBox *d_boxes = nullptr;
   int nbox = 0;
   long long count_cache = -1;
-  u64 *d_res = nullptr;        // MGX_RES_WORDS words
+  u64 *d_res = nullptr;        // record 0, the replicas and the commit count (MGX_RES_TOTAL_WORDS words)
+  bool slots_dirty = false;    // a kernel that does not fold its own replicas has committed since the last reset or fold
   MgxSolveState *d_solve = nullptr;   // state + history of mgx_level_solve (allocated on first use)
   MgxFusedPlan plan;           // tile lists of the fused sweep (rebuilt when the boxes change)
   MgxFusedPlan plan2;          // tile lists of the two-sweeps-per-pass kernel
@@ -129,11 +130,12 @@ struct MgxTransferPlan {
 static inline mgx_ctx *C(mgx_level *lv) { return lv->ctx; }
 
 static MgxLevelState level_state(const mgx_level *lv) {
-  return MgxLevelState{lv->cur, lv->shell_synced, lv->defined, lv->inner_pending, lv->zero_pending};
+  return MgxLevelState{lv->cur, lv->shell_synced, lv->defined, lv->inner_pending, lv->zero_pending, lv->slots_dirty};
 }
 static void set_level_state(mgx_level *lv, const MgxLevelState &s) {
   lv->cur = s.cur; lv->shell_synced = s.shell_synced; lv->defined = s.defined; lv->inner_pending = s.inner_pending;
   lv->zero_pending = s.zero_pending;
+  lv->slots_dirty = s.slots_dirty;
 }
 
 template <typename T>
@@ -177,6 +179,8 @@ extern "C" int mgx_ctx_create(int device, void *stream, mgx_ctx **out) {
   if (const char *e = getenv("MGX_FUSED_NW")) mgx_fused_nw = atoi(e);
   if (const char *e = getenv("MGX_FUSED_ZC")) mgx_fused_zc = atoi(e);
   if (const char *e = getenv("MGX_FUSED_TAIL")) mgx_fused_tail = atoi(e);
+  if (const char *e = getenv("MGX_FUSED_ORDER")) mgx_fused_order = atoi(e);
+  if (const char *e = getenv("MGX_FUSED_BOXCUT")) mgx_fused_boxcut = atoi(e);
   if (const char *e = getenv("MGX_PAIR_PASS")) mgx_pair_pass = atoi(e);   // 0 off, 1 on every level the kernel takes
   if (stream) {
     c->stream = (hipStream_t)stream;
@@ -280,7 +284,7 @@ static MgxLevelState level_state(const mgx_level *lv);
 static void set_level_state(mgx_level *lv, const MgxLevelState &s);
 static bool same_state(const MgxLevelState &a, const MgxLevelState &b) {
   return a.cur == b.cur && a.shell_synced == b.shell_synced && a.defined == b.defined &&
-         a.inner_pending == b.inner_pending && a.zero_pending == b.zero_pending;
+         a.inner_pending == b.inner_pending && a.zero_pending == b.zero_pending && a.slots_dirty == b.slots_dirty;
 }
 
 extern "C" int mgx_ctx_capture_begin(mgx_ctx *ctx) {
@@ -407,11 +411,11 @@ extern "C" int mgx_level_create_slab(mgx_ctx *ctx, int layer, const int32_t n[3]
       return fail(MGX_ENOMEM, "mgx_level_create: hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
     }
   }
-  hipError_t e = hipMalloc((void **)&lv->d_res, MGX_RES_WORDS * (1 + MGX_RES_SLOTS) * sizeof(u64));
+  hipError_t e = hipMalloc((void **)&lv->d_res, MGX_RES_TOTAL_WORDS * sizeof(u64));
   if (e != hipSuccess) { (void)hipFree(lv->buf[0]); (void)hipFree(lv->buf[1]); delete lv; return fail(MGX_ENOMEM, "hipMalloc(result)"); }
   if (hipMemsetAsync(lv->buf[0], 0, bytes, ctx->stream) != hipSuccess ||
       hipMemsetAsync(lv->buf[1], 0, bytes, ctx->stream) != hipSuccess ||
-      hipMemsetAsync(lv->d_res, 0, MGX_RES_WORDS * (1 + MGX_RES_SLOTS) * sizeof(u64), ctx->stream) != hipSuccess) {
+      hipMemsetAsync(lv->d_res, 0, MGX_RES_TOTAL_WORDS * sizeof(u64), ctx->stream) != hipSuccess) {
     (void)hipStreamSynchronize(ctx->stream);
     (void)hipFree(lv->buf[0]); (void)hipFree(lv->buf[1]); (void)hipFree(lv->d_res);
     delete lv;
@@ -495,6 +499,12 @@ extern "C" int mgx_level_set_boxes(mgx_level *lv, int32_t nbox, const int32_t *p
     b.constant = constant[i] != 0;
     if (!(rho[i] >= 0.0)) return fail(MGX_EINVAL, "mgx_level_set_boxes: box %d has rho < 0 (t_mg.f90:352)", i);
     b.val = lv->elem == 4 ? (double)(float)val[i] : val[i];   // box%val is real(grid_p)
+    // the convergence sum adds |V| exactly for |V| < 2^20 (mgx_exact_add); a potential that starts at half that range
+    // would leave it with the first over-relaxed step, and the stop that follows would read like a divergence
+    // (any box: grid_setup imprints the value of the FIRST box that holds a constant cell, t_mg.f90:651-668)
+    if (!(std::fabs(b.val) < 524288.0))
+      return fail(MGX_ELIMIT, "mgx_level_set_boxes: box %d has |value| = %g; values must stay below 2^19 = 524288 "
+                  "(the exact sum of |V| that decides convergence covers |V| < 2^20): rescale the potential", i, b.val);
     b.rho = lv->elem == 4 ? (double)(float)rho[i] : rho[i];
     b.rho_is_one = b.rho == 1.0;
   }
@@ -583,8 +593,14 @@ extern "C" int mgx_level_setup(mgx_level *lv, int init) {
 // sweeps
 
 static int reset_result(mgx_level *lv) {
-  HIP_TRY(hipMemsetAsync(lv->d_res, 0, MGX_RES_WORDS * (1 + MGX_RES_SLOTS) * sizeof(u64), C(lv)->stream));
+  HIP_TRY(hipMemsetAsync(lv->d_res, 0, MGX_RES_TOTAL_WORDS * sizeof(u64), C(lv)->stream));
+  lv->slots_dirty = false;
   return MGX_OK;
+}
+// before a launch of a tiled sweep kernel with reductions: those kernels fold their own replicas and leave them zero
+// (mgx_block_commit with a count), so only what other kernels left behind has to be cleared
+static int prepare_single_pass(mgx_level *lv) {
+  return lv->slots_dirty ? reset_result(lv) : MGX_OK;
 }
 
 extern "C" int mgx_level_result_reset(mgx_level *lv) {
@@ -644,7 +660,7 @@ static int do_sweeps(mgx_level *lv, int nsweeps, int reduce) {
     if (which == MGX_KERNEL_FUSED && s + 2 <= nsweeps && pair_pass_wanted<T>(lv)) {
       // two sweeps in one pass over the field (gs_V's legs run their sweeps back to back, m_gs_CDS.F90:240-242)
       const int red = (s + 2 == nsweeps) ? reduce : 0;
-      if (red) TRY(reset_result(lv));
+      if (red) TRY(prepare_single_pass(lv));
       TRY(sync_shell<T>(lv));
       if (!lv->plan2.valid) NOT_WHILE_CAPTURING(C(lv), "mgx_level_sweep (first pair pass of a level builds its tile lists)");
       if (!lv->plan2.valid && mgx_fused_make_plan(lv->plan2, g, lv->boxes, C(lv)->stream, 2) != 0)
@@ -659,7 +675,7 @@ static int do_sweeps(mgx_level *lv, int nsweeps, int reduce) {
       continue;
     }
     const int red = (s == nsweeps - 1) ? reduce : 0;
-    if (red) TRY(reset_result(lv));
+    if (red) TRY(which == MGX_KERNEL_FUSED ? prepare_single_pass(lv) : reset_result(lv));
     if (which == MGX_KERNEL_FUSED) {
       TRY(sync_shell<T>(lv));
       if (!lv->plan.valid) NOT_WHILE_CAPTURING(C(lv), "mgx_level_sweep (first sweep of a level builds its tile lists)");
@@ -673,6 +689,7 @@ static int do_sweeps(mgx_level *lv, int nsweeps, int reduce) {
     } else {
       TRY(launch_half<T>(lv, 1, 1, g.n3, red));
       TRY(launch_half<T>(lv, 0, 1, g.n3, red));
+      if (red) lv->slots_dirty = true;
     }
   }
   return MGX_OK;
@@ -709,7 +726,7 @@ static int do_sweep_part(mgx_level *lv, int part, int reduce) {
                 MGX_MAX_FUSED_BOXES);
   if (part == MGX_PART_EDGE) {
     if (lv->inner_pending) return fail(MGX_ESTATE, "mgx_level_sweep_part: the inner part of the previous sweep is still due");
-    if (reduce) TRY(reset_result(lv));
+    if (reduce) TRY(prepare_single_pass(lv));
     TRY(sync_shell<T>(lv));
     if (!lv->plan.valid) NOT_WHILE_CAPTURING(C(lv), "mgx_level_sweep_part (first sweep of a level builds its tile lists)");
     if (!lv->plan.valid && mgx_fused_make_plan(lv->plan, g, lv->boxes, C(lv)->stream) != 0)
@@ -749,6 +766,7 @@ extern "C" int mgx_level_half_sweep(mgx_level *lv, int parity, int32_t zlo, int3
   if (zlo > zhi) return MGX_OK;
   TRY(set_device(C(lv)));
   TRY(materialize(lv));
+  if (reduce) lv->slots_dirty = true;
   return lv->elem == 4 ? launch_half<float>(lv, parity, zlo, zhi, reduce) : launch_half<double>(lv, parity, zlo, zhi, reduce);
 }
 
@@ -772,7 +790,7 @@ static int do_solve(mgx_level *lv, double tol_level, double nr, double old_sum, 
   init.stop = 0; init.count = 0; init.old_sum = (double)(T)old_sum;
   HIP_TRY(hipMemcpyAsync(lv->d_solve, &init, sizeof init, hipMemcpyHostToDevice, st));
   HIP_TRY(hipStreamSynchronize(st));                       // `init` is a local
-  TRY(reset_result(lv));
+  TRY(prepare_single_pass(lv));
   const MgxSweepParams<T> p = make_params<T>(lv);
   long long done = 0;
   *status = 0;
@@ -785,7 +803,7 @@ static int do_solve(mgx_level *lv, double tol_level, double nr, double old_sum, 
       if (mgx_fused_launch(lv->plan, 0, (const T *)lv->buf[a], (T *)lv->buf[1 - a], g, p, lv->d_boxes, lv->nbox,
                            MGX_RED_ERR | MGX_RED_SUM, lv->d_res, st, &lv->d_solve->stop) != 0)
         return fail(MGX_EHIP, "mgx_level_solve: fused kernel launch configuration failed");
-      hipLaunchKernelGGL((k_solve_check<T>), dim3(1), dim3(MGX_RES_SLOTS), 0, st, lv->d_res, lv->d_solve, d_hist, MGX_SOLVE_BATCH,
+      hipLaunchKernelGGL((k_solve_check<T>), dim3(1), dim3(64), 0, st, (const u64 *)lv->d_res, lv->d_solve, d_hist, MGX_SOLVE_BATCH,
                          tol_level, nr);
     }
     HIP_TRY(hipGetLastError());
@@ -853,8 +871,11 @@ extern "C" double mgx_limbs_to_double(const uint64_t limbs[2]) {
 
 static int fetch_result(mgx_level *lv, double *err, double *sum, uint64_t limbs_out[2]) {
   mgx_ctx *c = C(lv);
-  hipLaunchKernelGGL(k_fold_result, dim3(1), dim3(MGX_RES_SLOTS), 0, c->stream, lv->d_res);
-  HIP_TRY(hipGetLastError());
+  if (lv->slots_dirty) {      // the tiled sweep kernels leave their result folded; the others leave replicas
+    hipLaunchKernelGGL(k_fold_result, dim3(1), dim3(MGX_RES_SLOTS), 0, c->stream, lv->d_res);
+    HIP_TRY(hipGetLastError());
+    lv->slots_dirty = false;
+  }
   HIP_TRY(hipMemcpyAsync(c->h_res, lv->d_res, MGX_RES_WORDS * sizeof(u64), hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
   const u64 *r = c->h_res;
@@ -893,6 +914,7 @@ extern "C" int mgx_level_abs_sum_limbs(mgx_level *lv, uint64_t limbs[2]) {
   TRY(materialize(lv));
   TRY(reset_result(lv));
   TRY(lv->elem == 4 ? launch_abs_sum<float>(lv) : launch_abs_sum<double>(lv));
+  lv->slots_dirty = true;
   double s;
   TRY(fetch_result(lv, nullptr, &s, limbs));
   if (std::isnan(s)) return fail(MGX_ELIMIT, "mgx_level_abs_sum: a value is >= 2^20 or not finite");

@@ -121,3 +121,8 @@ __device__ inline void mgx_fast_sum_flush(double &h, double &l, u64 &lo, u64 &hi
 // Blocks commit into one of MGX_RES_SLOTS replicas of the record (by block index) so that thousands of
 // blocks do not queue on one address; a one-block kernel folds the replicas into record 0 before read-back.
 #define MGX_RES_SLOTS 128
+// One more word behind the replicas counts the blocks of a launch that have committed (single-pass grid reduce of the
+// tiled sweep kernels: the block whose count comes last folds the replicas into record 0 and clears them).
+#define MGX_RES_SLOTS_SP 16      /* replicas such a launch uses (the first ones) */
+#define MGX_RES_CNT (MGX_RES_WORDS * (1 + MGX_RES_SLOTS))
+#define MGX_RES_TOTAL_WORDS (MGX_RES_CNT + MGX_RES_WORDS)

@@ -236,7 +236,7 @@ __device__ __forceinline__ void mgx_fused_body(const T *__restrict__ src, T *__r
                                                const MgxSweepParams<T> &p, const MgxBox *__restrict__ bx, const int nb,
                                                const int tx0, const int ty0, const int zc0, const int zc1,
                                                const int reduce, u64 *__restrict__ res, T *__restrict__ lds,
-                                               MgxBoxLds<T> *__restrict__ bl) {
+                                               MgxBoxLds<T> *__restrict__ bl, const int n_commit) {
   typedef typename MgxVec2<T>::type V2;
   constexpr int TXP = 64;
   constexpr int LP = TXP + 2;            // pairs per staged row
@@ -591,7 +591,7 @@ __device__ __forceinline__ void mgx_fused_body(const T *__restrict__ src, T *__r
 #undef MGX_STAGE
 #undef MGX_Q
 
-  if (reduce) mgx_block_commit<NW + 1>((double)(err * err), slo, shi, ovf, reduce, res);
+  if (reduce) mgx_block_commit<NW + 1>((double)(err * err), slo, shi, ovf, reduce, res, n_commit);
 }
 
 // One launch per sweep.  `tiles` lists the pieces of work in dispatch order, three ints each: tile column (x
@@ -603,7 +603,8 @@ template <typename T, int TY, int BOXES, int NW>
 __device__ __forceinline__ void mgx_fused_tile(const T *__restrict__ src, T *__restrict__ dst, const MgxGeom &g,
                                                const MgxSweepParams<T> &p, const MgxBox *__restrict__ bx, const int nb,
                                                const int ntx, const int tile, const int zc0, const int zc1, const int reduce,
-                                               u64 *__restrict__ res, T *__restrict__ lds, MgxBoxLds<T> *__restrict__ bl) {
+                                               u64 *__restrict__ res, T *__restrict__ lds, MgxBoxLds<T> *__restrict__ bl,
+                                               const int n_commit) {
   constexpr int TXP = 64;
   const int tx = tile % ntx, ty = tile / ntx;
   const int tx0 = 1 + tx * 2 * TXP, ty0 = 1 + ty * TY;
@@ -614,14 +615,14 @@ __device__ __forceinline__ void mgx_fused_tile(const T *__restrict__ src, T *__r
   // (see FREE above) staged rows ty0-2 .. ty0+TY+1 and columns tx0 .. tx0+127 all interior
   const bool free_rows = BOXES == 0 && ty0 - 2 >= 1 && ty0 + TY + 1 <= g.n2 && tx0 + 2 * TXP - 1 <= g.n1;
   if (halo) {
-    if (p0) mgx_fused_body<T, TY, BOXES, NW, 1, true>(src, dst, g, p, bx, nb, tx0, ty0, zc0, zc1, reduce, res, lds, bl);
-    else mgx_fused_body<T, TY, BOXES, NW, 0, true>(src, dst, g, p, bx, nb, tx0, ty0, zc0, zc1, reduce, res, lds, bl);
+    if (p0) mgx_fused_body<T, TY, BOXES, NW, 1, true>(src, dst, g, p, bx, nb, tx0, ty0, zc0, zc1, reduce, res, lds, bl, n_commit);
+    else mgx_fused_body<T, TY, BOXES, NW, 0, true>(src, dst, g, p, bx, nb, tx0, ty0, zc0, zc1, reduce, res, lds, bl, n_commit);
   } else if (BOXES == 0 && free_rows) {
-    if (p0) mgx_fused_body<T, TY, 0, NW, 1, false, true>(src, dst, g, p, bx, nb, tx0, ty0, zc0, zc1, reduce, res, lds, bl);
-    else mgx_fused_body<T, TY, 0, NW, 0, false, true>(src, dst, g, p, bx, nb, tx0, ty0, zc0, zc1, reduce, res, lds, bl);
+    if (p0) mgx_fused_body<T, TY, 0, NW, 1, false, true>(src, dst, g, p, bx, nb, tx0, ty0, zc0, zc1, reduce, res, lds, bl, n_commit);
+    else mgx_fused_body<T, TY, 0, NW, 0, false, true>(src, dst, g, p, bx, nb, tx0, ty0, zc0, zc1, reduce, res, lds, bl, n_commit);
   } else {
-    if (p0) mgx_fused_body<T, TY, BOXES, NW, 1, false>(src, dst, g, p, bx, nb, tx0, ty0, zc0, zc1, reduce, res, lds, bl);
-    else mgx_fused_body<T, TY, BOXES, NW, 0, false>(src, dst, g, p, bx, nb, tx0, ty0, zc0, zc1, reduce, res, lds, bl);
+    if (p0) mgx_fused_body<T, TY, BOXES, NW, 1, false>(src, dst, g, p, bx, nb, tx0, ty0, zc0, zc1, reduce, res, lds, bl, n_commit);
+    else mgx_fused_body<T, TY, BOXES, NW, 0, false>(src, dst, g, p, bx, nb, tx0, ty0, zc0, zc1, reduce, res, lds, bl, n_commit);
   }
 }
 
@@ -629,7 +630,7 @@ template <typename T, int TY, int NW>
 __global__ __launch_bounds__((NW + 1) * 64) void k_fused_sweep(const T *__restrict__ src, T *__restrict__ dst, const MgxGeom g,
                                                      const MgxSweepParams<T> p, const MgxBox *__restrict__ bx,
                                                      const int nb, const int ntx,
-                                                     const int *__restrict__ tiles, const int n_box, const int n_const,
+                                                     const int *__restrict__ tiles, const int n_commit,
                                                      const int reduce, u64 *__restrict__ res,
                                                      const int *__restrict__ stop) {
   constexpr int TXP = 64;
@@ -641,12 +642,12 @@ __global__ __launch_bounds__((NW + 1) * 64) void k_fused_sweep(const T *__restri
   MgxBoxLds<T> *bl = reinterpret_cast<MgxBoxLds<T> *>(lds + 3 * 2 * (TXP + 2) * (TY + 6));
 
   const int b = blockIdx.x;
-  const int cls = b < n_box ? 2 : b < n_box + n_const ? 1 : 0;
-  const int tile = tiles[3 * b], zc0 = tiles[3 * b + 1], zc1 = tiles[3 * b + 2];
-  if (tile < 0) return;                                 // padding (the whole block leaves before any barrier)
-  if (cls == 2) mgx_fused_tile<T, TY, 2, NW>(src, dst, g, p, bx, nb, ntx, tile, zc0, zc1, reduce, res, lds, bl);
-  else if (cls == 1) mgx_fused_tile<T, TY, 1, NW>(src, dst, g, p, bx, nb, ntx, tile, zc0, zc1, reduce, res, lds, bl);
-  else mgx_fused_tile<T, TY, 0, NW>(src, dst, g, p, bx, nb, ntx, tile, zc0, zc1, reduce, res, lds, bl);
+  const int entry = tiles[3 * b], zc0 = tiles[3 * b + 1], zc1 = tiles[3 * b + 2];
+  if (entry < 0) return;                                 // padding (the whole block leaves before any barrier)
+  const int cls = entry >> MGX_TILE_CLASS_SHIFT, tile = entry & ((1 << MGX_TILE_CLASS_SHIFT) - 1);
+  if (cls == 2) mgx_fused_tile<T, TY, 2, NW>(src, dst, g, p, bx, nb, ntx, tile, zc0, zc1, reduce, res, lds, bl, n_commit);
+  else if (cls == 1) mgx_fused_tile<T, TY, 1, NW>(src, dst, g, p, bx, nb, ntx, tile, zc0, zc1, reduce, res, lds, bl, n_commit);
+  else mgx_fused_tile<T, TY, 0, NW>(src, dst, g, p, bx, nb, ntx, tile, zc0, zc1, reduce, res, lds, bl, n_commit);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -673,7 +674,7 @@ static int mgx_fused_launch_cfg(const MgxFusedPlan &pl, int part, const T *src, 
   const int total = tl.n_box + tl.n_const + tl.n_fast;
   if (total > 0)
     hipLaunchKernelGGL((k_fused_sweep<T, TY, NW>), dim3((unsigned)total), dim3((NW + 1) * 64), lds, st, src, dst, g, p, bx, nb,
-                       pl.ntx, pl.d_tiles + 3 * tl.offset, tl.n_box, tl.n_const, reduce, res, stop);
+                       pl.ntx, pl.d_tiles + 3 * tl.offset, reduce ? pl.list[0].n_real : 0, reduce, res, stop);
   return 0;
 }
 

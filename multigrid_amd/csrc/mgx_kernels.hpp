@@ -24,8 +24,16 @@ __device__ inline u64 mgx_wave_add(u64 v) {
 }
 
 // NW = waves per block.  Every thread of the block must call this.
+// expected = 0: the block only commits into its replica (the replicas were cleared before the launch and a later
+// kernel, k_fold_result, folds them).  expected > 0 (the number of blocks that commit in this launch, or in the
+// launches that share one result): single-pass grid reduce.  Every block counts itself after its atomics have reached
+// memory; the block whose count is the last one reads the replicas back with atomic exchanges (atomics on both sides of
+// the hand-off, so no cache has to be flushed or invalidated), which also leaves them zero for the next launch, writes
+// the folded result to record 0 and clears the count.  Nothing has to be zeroed before such a launch and nothing
+// folded after it.
 template <int NW>
-__device__ inline void mgx_block_commit(double err, u64 lo, u64 hi, unsigned ovf, int reduce, u64 *res) {
+__device__ inline void mgx_block_commit(double err, u64 lo, u64 hi, unsigned ovf, int reduce, u64 *res,
+                                        const int expected = 0) {
   __shared__ u64 sh[NW][6];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
   if (reduce & 1) {
@@ -42,7 +50,10 @@ __device__ inline void mgx_block_commit(double err, u64 lo, u64 hi, unsigned ovf
   }
   __syncthreads();
   if (threadIdx.x == 0) {
-    res += MGX_RES_WORDS * (1 + (blockIdx.x + blockIdx.y * 7 + blockIdx.z * 13) % MGX_RES_SLOTS);
+    u64 *const res0 = res;
+    // (a launch that folds its own replicas has at most a few thousand blocks, which commit as they finish: a few
+    // replicas keep them apart and the last block has little to fold)
+    res += MGX_RES_WORDS * (1 + (blockIdx.x + blockIdx.y * 7 + blockIdx.z * 13) % (expected > 0 ? MGX_RES_SLOTS_SP : MGX_RES_SLOTS));
     if (reduce & 1) {
       u64 m = sh[0][0];
 #pragma unroll
@@ -60,21 +71,57 @@ __device__ inline void mgx_block_commit(double err, u64 lo, u64 hi, unsigned ovf
         if (d[k]) atomicAdd(&res[1 + k], d[k]);
       if (d[4]) atomicAdd(&res[5], d[4]);
     }
+    res = res0;
+  }
+  if (expected > 0 && threadIdx.x < 64) {          // wave 0 (thread 0 is its first lane)
+    int last = 0;
+    if (threadIdx.x == 0) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // this block's atomics are in memory before it is counted
+      last = atomicAdd(&res[MGX_RES_CNT], 1ull) + 1ull == (u64)expected;
+    }
+    last = __shfl(last, 0, 64);
+    if (last) {
+      u64 m = 0ull, d[5] = {0ull, 0ull, 0ull, 0ull, 0ull};
+      for (int sl = lane; sl < MGX_RES_SLOTS_SP; sl += 64) {
+        u64 *mine = res + MGX_RES_WORDS * (1 + sl);
+        const u64 a0 = atomicExch(&mine[0], 0ull);
+        u64 a[5];
+#pragma unroll
+        for (int k = 0; k < 5; ++k) a[k] = atomicExch(&mine[1 + k], 0ull);
+        m = a0 > m ? a0 : m;
+#pragma unroll
+        for (int k = 0; k < 5; ++k) d[k] += a[k];
+      }
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) { const u64 t = __shfl_xor(m, o, 64); m = t > m ? t : m; }
+#pragma unroll
+      for (int k = 0; k < 5; ++k) d[k] = mgx_wave_add(d[k]);
+      if (lane == 0) {
+        res[0] = m;
+#pragma unroll
+        for (int k = 0; k < 5; ++k) res[1 + k] = d[k];
+        atomicExch(&res[MGX_RES_CNT], 0ull);
+      }
+    }
   }
 }
 
-// fold the replicas into record 0 (max of word 0, sums of words 1..5); one block of MGX_RES_SLOTS threads
+// fold the replicas into record 0 (max of word 0, sums of words 1..5) and clear them: record 0 then holds everything
+// committed since the last reset, whether a launch folded its own replicas (mgx_block_commit with a count) or not;
+// folding again changes nothing.  One block of MGX_RES_SLOTS threads
 // (not a template: defined in the translation unit that launches it)
 #ifdef MGX_MAIN_UNIT
 __global__ __launch_bounds__(MGX_RES_SLOTS) void k_fold_result(u64 *__restrict__ res) {
   __shared__ u64 sh[MGX_RES_SLOTS / 64][6];
-  const u64 *mine = res + MGX_RES_WORDS * (1 + threadIdx.x);
+  u64 *mine = res + MGX_RES_WORDS * (1 + threadIdx.x);
   u64 m = mine[0];
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) { const u64 t = __shfl_xor(m, o, 64); m = t > m ? t : m; }
   u64 d[5];
 #pragma unroll
   for (int k = 0; k < 5; ++k) d[k] = mgx_wave_add(mine[1 + k]);
+#pragma unroll
+  for (int k = 0; k < 6; ++k) mine[k] = 0ull;
   const int w = threadIdx.x >> 6;
   if ((threadIdx.x & 63) == 0) { sh[w][0] = m; for (int k = 0; k < 5; ++k) sh[w][1 + k] = d[k]; }
   __syncthreads();
@@ -84,8 +131,8 @@ __global__ __launch_bounds__(MGX_RES_SLOTS) void k_fold_result(u64 *__restrict__
       mm = sh[i][0] > mm ? sh[i][0] : mm;
       for (int k = 0; k < 5; ++k) dd[k] += sh[i][1 + k];
     }
-    res[0] = mm;
-    for (int k = 0; k < 5; ++k) res[1 + k] = dd[k];
+    res[0] = res[0] > mm ? res[0] : mm;
+    for (int k = 0; k < 5; ++k) res[1 + k] += dd[k];
   }
 }
 #endif
@@ -125,58 +172,31 @@ struct MgxSolveState {      // device memory, one per level that mgx_level_solve
   double old_sum;           // grid_sum before the next sweep, already rounded to the level's precision
 };
 
-// After a sweep with both reductions: fold the result replicas, evaluate tol = |old_sum - new_sum| * nr in the level's
-// precision T (m_gs_CDS.F90:206-207), append (tol, new_sum, max dV^2) to the batch's history and raise `stop` when
-// the loop condition `tol > gtol` (:200) fails.  While the loop goes on the replicas are cleared for the next sweep;
-// when it ends the folded result is left in replica 1 (a later fold finds it).  One block of MGX_RES_SLOTS threads.
+// After a sweep with both reductions (whose last block has folded the result into record 0): evaluate
+// tol = |old_sum - new_sum| * nr in the level's precision T (m_gs_CDS.F90:206-207), append (tol, new_sum, max dV^2) to
+// the batch's history and raise `stop` when the loop condition `tol > gtol` (:200) fails.  One thread.
 template <typename T>
-__global__ __launch_bounds__(MGX_RES_SLOTS) void k_solve_check(u64 *__restrict__ res, MgxSolveState *__restrict__ stt,
-                                                               double *__restrict__ hist, const int cap, const double gtol,
-                                                               const double nr) {
-  if (stt->stop != 0) return;
-  __shared__ u64 sh[MGX_RES_SLOTS / 64][6];
-  u64 *mine = res + MGX_RES_WORDS * (1 + threadIdx.x);
-  u64 m = mine[0];
-  u64 d[5];
-#pragma unroll
-  for (int k = 0; k < 5; ++k) d[k] = mine[1 + k];
-#pragma unroll
-  for (int k = 0; k < 6; ++k) mine[k] = 0ull;
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1) { const u64 t = __shfl_xor(m, o, 64); m = t > m ? t : m; }
-#pragma unroll
-  for (int k = 0; k < 5; ++k) d[k] = mgx_wave_add(d[k]);
-  const int w = threadIdx.x >> 6;
-  if ((threadIdx.x & 63) == 0) { sh[w][0] = m; for (int k = 0; k < 5; ++k) sh[w][1 + k] = d[k]; }
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    u64 mm = sh[0][0], dd[5] = {sh[0][1], sh[0][2], sh[0][3], sh[0][4], sh[0][5]};
-    for (int i = 1; i < MGX_RES_SLOTS / 64; ++i) {
-      mm = sh[i][0] > mm ? sh[i][0] : mm;
-      for (int k = 0; k < 5; ++k) dd[k] += sh[i][1 + k];
-    }
-    // positional sum of the four digits (they may exceed 32 bits)
-    u64 lo = dd[0], hi = dd[2] + (dd[3] << 32);
-    const u64 a = dd[1] << 32;
-    lo += a;
-    hi += (dd[1] >> 32) + (lo < a ? 1ull : 0ull);
-    const bool bad = dd[4] != 0ull;
-    const double sum = bad ? __longlong_as_double(0x7ff8000000000000LL) : mgx_limbs_to_double_dev(lo, hi);
-    const T new_sum = (T)sum, old_sum = (T)stt->old_sum;
-    const T diff = old_sum - new_sum;
-    const T tol = (diff < (T)0 ? -diff : diff) * (T)nr;
-    const int i = stt->count;
-    if (i < cap) { hist[3 * i] = (double)tol; hist[3 * i + 1] = (double)new_sum; hist[3 * i + 2] = __longlong_as_double((long long)mm); }
-    stt->count = i + 1;
-    stt->old_sum = (double)new_sum;
-    const int stop = bad ? 2 : ((double)tol > gtol ? 0 : 1);
-    stt->stop = stop;
-    if (stop) {                        // leave the last sweep's result where mgx_level_result finds it
-      u64 *r1 = res + MGX_RES_WORDS;
-      r1[0] = mm;
-      for (int k = 0; k < 5; ++k) r1[1 + k] = dd[k];
-    }
-  }
+__global__ __launch_bounds__(64) void k_solve_check(const u64 *__restrict__ res, MgxSolveState *__restrict__ stt,
+                                                    double *__restrict__ hist, const int cap, const double gtol,
+                                                    const double nr) {
+  if (threadIdx.x != 0 || stt->stop != 0) return;
+  const u64 mm = res[0];
+  const u64 dd[5] = {res[1], res[2], res[3], res[4], res[5]};
+  // positional sum of the four digits (they may exceed 32 bits)
+  u64 lo = dd[0], hi = dd[2] + (dd[3] << 32);
+  const u64 a = dd[1] << 32;
+  lo += a;
+  hi += (dd[1] >> 32) + (lo < a ? 1ull : 0ull);
+  const bool bad = dd[4] != 0ull;
+  const double sum = bad ? __longlong_as_double(0x7ff8000000000000LL) : mgx_limbs_to_double_dev(lo, hi);
+  const T new_sum = (T)sum, old_sum = (T)stt->old_sum;
+  const T diff = old_sum - new_sum;
+  const T tol = (diff < (T)0 ? -diff : diff) * (T)nr;
+  const int i = stt->count;
+  if (i < cap) { hist[3 * i] = (double)tol; hist[3 * i + 1] = (double)new_sum; hist[3 * i + 2] = __longlong_as_double((long long)mm); }
+  stt->count = i + 1;
+  stt->old_sum = (double)new_sum;
+  stt->stop = bad ? 2 : ((double)tol > gtol ? 0 : 1);
 }
 
 // ------------------------------------------------------------------------------------------------

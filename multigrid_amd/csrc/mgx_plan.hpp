@@ -8,9 +8,16 @@
 #include "mgx_common.hpp"
 
 #define MGX_MAX_FUSED_BOXES 32
+#define MGX_TILE_CLASS_SHIFT 28   /* tile list entries: tile column | class << 28 (0 box-free, 1 rho = 1 boxes only, 2 some rho != 1 box) */
+// tile height and row waves of the two-sweeps-per-pass kernel (the tile lists and the kernel must agree)
+#ifndef MGX_TB_TY
+#define MGX_TB_TY 22
+#define MGX_TB_NW 6
+#endif
 
 struct MgxTileList {             // segment sizes, each padded to a multiple of 8, and where the list starts
   int n_fast = 0, n_const = 0, n_box = 0;
+  int n_real = 0;                // entries that are pieces of work (the blocks that commit reductions)
   int offset = 0;                // entry (3 ints each) in MgxFusedPlan::d_tiles: n_box entries, n_const, n_fast; -1 = padding
 };
 
@@ -29,6 +36,8 @@ static int mgx_fused_nw = 0;     // row waves per block override (4 or 8)
 #define MGX_EDGE_PLANES 8        /* planes at either end of a slab swept ahead of the halo exchange */
 static int mgx_fused_zc = 0;     // z chunk override (0 = automatic)
 static int mgx_fused_tail = -1;  // percent of the box-free chunks cut into halves, and half as many again into quarters (-1 = automatic)
+static int mgx_fused_order = 0;  // dispatch order of the groups of pieces, for benchmarking (see mgx_fused_make_plan)
+static int mgx_fused_boxcut = 1; // parts the chunks that boxes reach are cut into
 
 // (re)build the plan: which tiles can any box reach?  A tile asks about cells of its footprint grown by
 // one and about their neighbours, i.e. positions grown by two, on planes zc0-2 .. zc1+2.
@@ -47,7 +56,7 @@ static int mgx_fused_make_plan(MgxFusedPlan &pl, const MgxGeom &g, const std::ve
       pl.ty = mgx_fused_ty; pl.nw = mgx_fused_nw;
     }
   }
-  if (ns == 2) { pl.ty = 22; pl.nw = 6; }      // the temporally blocked kernel: 128 x 22 tiles on 6 row waves
+  if (ns == 2) { pl.ty = MGX_TB_TY; pl.nw = MGX_TB_NW; }   // the temporally blocked kernel: 128 x 22 tiles on 6 row waves
   pl.ntx = (g.n1 + 2 * TXP - 1) / (2 * TXP);
   pl.nty = (g.n2 + pl.ty - 1) / pl.ty;
   // z chunk: at least three rounds of blocks on 256 compute units (tiles differ in cost: the rounds even that
@@ -64,7 +73,7 @@ static int mgx_fused_make_plan(MgxFusedPlan &pl, const MgxGeom &g, const std::ve
   pl.ZC = ZC;
   pl.nzc = (g.n3 + ZC - 1) / ZC;
   const long long ntile = per_chunk * pl.nzc;
-  if (ntile > 0x7fffffffLL) return -1;
+  if (ntile > 0x0fffffffLL) return -1;
   // Blocks are dispatched in index order, block b to XCD b mod 8, one block per compute unit.  Chunks that differ
   // in cost must therefore come in groups of 8 equal ones (or an XCD that got the long ones holds up the
   // dispatch of all), and the last blocks to start decide when the sweep ends: of the box-free chunks of a large
@@ -104,6 +113,14 @@ static int mgx_fused_make_plan(MgxFusedPlan &pl, const MgxGeom &g, const std::ve
       for (int ty = 0; ty < pl.nty; ++ty)
         for (int tx = 0; tx < pl.ntx; ++tx) {
           const int c = classify(tx, ty, zc0, zc1);
+          if (c != 0 && mgx_fused_boxcut > 1 && zc1 - zc0 + 1 >= 8 * mgx_fused_boxcut) {
+            const int len = zc1 - zc0 + 1, plen = (len + mgx_fused_boxcut - 1) / mgx_fused_boxcut;
+            for (int a = zc0; a <= zc1; a += plen) {          // classified again: a part may lie outside every box
+              const int b2 = std::min(a + plen - 1, zc1), c2 = classify(tx, ty, a, b2);
+              (c2 == 2 ? grp[0] : c2 == 1 ? grp[1] : grp[3]).push_back({ty * pl.ntx + tx, a, b2});
+            }
+            continue;
+          }
           (c == 2 ? grp[0] : c == 1 ? grp[1] : carved ? grp[4] : fast).push_back({ty * pl.ntx + tx, zc0, zc1});
         }
     }
@@ -120,21 +137,29 @@ static int mgx_fused_make_plan(MgxFusedPlan &pl, const MgxGeom &g, const std::ve
   for (int sel = 0; sel < 3; ++sel) {
     MgxTileList &tl = pl.list[sel];
     tl.offset = (int)all.size() / 3;
-    int count[3] = {0, 0, 0};
-    for (int gi = 0; gi < 5; ++gi) {
+    int count[3] = {0, 0, 0}, n_real = 0;
+    // order 0: pieces that boxes reach first (they take longest); 1: box-free whole chunks first (they start and
+    // stay in step, so neighbouring tiles meet in L2), then the box pieces, then the cut tail; 2: box pieces between
+    // the halves and the quarters of the tail
+    static const int orders[3][5] = {{0, 1, 2, 3, 4}, {2, 0, 1, 3, 4}, {2, 3, 0, 1, 4}};
+    for (int go = 0; go < 5; ++go) {
+      const int gi = orders[mgx_fused_order >= 0 && mgx_fused_order < 3 ? mgx_fused_order : 0][go];
       std::vector<Piece> v;
       for (const Piece &q : grp[gi]) {
         const bool edge = q.z0 <= 2 || q.z1 >= g.n3 - 1;     // holds plane 1, 2, n3-1 or n3
         if (sel == 0 || (sel == 1) == edge) v.push_back(q);
       }
+      n_real += (int)v.size();
       while (v.size() % 8) v.push_back({-1, 0, 0});
       const size_t per = v.size() / 8;
+      const int cls = gi == 0 ? 2 : gi == 1 ? 1 : 0;         // travels in the top bits of the tile column
       for (size_t i = 0; i < v.size(); ++i) {                // block i of the group runs on XCD i mod 8: give every
         const Piece &q = v[(i & 7) * per + (i >> 3)];        // XCD a contiguous run of the group (neighbouring tiles)
-        all.push_back(q.col); all.push_back(q.z0); all.push_back(q.z1);
+        all.push_back(q.col < 0 ? -1 : (q.col | (cls << MGX_TILE_CLASS_SHIFT))); all.push_back(q.z0); all.push_back(q.z1);
       }
       count[gi == 0 ? 0 : gi == 1 ? 1 : 2] += (int)v.size();
     }
+    tl.n_real = n_real;
     tl.n_box = count[0];
     tl.n_const = count[1];
     tl.n_fast = count[2];

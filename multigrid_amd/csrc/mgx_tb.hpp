@@ -70,7 +70,7 @@ __device__ __forceinline__ void mgx_tb_body(const T *__restrict__ src, T *__rest
                                             const MgxSweepParams<T> &p, const MgxBox *__restrict__ bx, const int nb,
                                             const int tx0, const int ty0, const int zc0, const int zc1,
                                             const int reduce, u64 *__restrict__ res, T *__restrict__ lds,
-                                            MgxBoxLds<T> *__restrict__ bl) {
+                                            MgxBoxLds<T> *__restrict__ bl, const int n_commit) {
   typedef typename MgxVec2<T>::type V2;
   constexpr int TXP = 64;
   constexpr int HP = NS;                   // halo pairs on either side of a row
@@ -84,7 +84,6 @@ __device__ __forceinline__ void mgx_tb_body(const T *__restrict__ src, T *__rest
   static_assert(LR % NW == 0 && NW % 2 == 0, "rows of a wave must share the parity of y");
   static_assert(LR % 2 == 0 && (LR / 2) * 2 * HP <= 64, "the halo pairs of two rows per lane must fit one wave");
   static_assert(DF == 1 || DF == 2, "one or two planes in flight");
-  static_assert(R <= 5, "codes of at most five pairs per lane");
   auto A = [&](int stage, int buf, int i) -> T & { return lds[(stage * 2 + buf) * PL + i]; };
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 
@@ -94,7 +93,7 @@ __device__ __forceinline__ void mgx_tb_body(const T *__restrict__ src, T *__rest
   unsigned fl[R];                          // bit 2 s + c: stage s may update cell c; bits 16, 17: cell counts in the reductions
   unsigned gob[R];                         // byte offset of the pair inside a plane
   bool st[R];
-  int rr[5] = {0, 0, 0, 0, 0};
+  int rr[R];
   int pcs = 0;
 #pragma unroll
   for (int j = 0; j < R; ++j) {
@@ -395,14 +394,15 @@ __device__ __forceinline__ void mgx_tb_body(const T *__restrict__ src, T *__rest
   }
 #undef MGX_TBQ
 #undef MGX_CMP
-  if (reduce & 3) mgx_block_commit<NW + 1>((double)(err * err), slo, shi, ovf, reduce & 3, res);
+  if (reduce & 3) mgx_block_commit<NW + 1>((double)(err * err), slo, shi, ovf, reduce & 3, res, n_commit);
 }
 
 template <typename T, int NS, int TY, int BOXES, int NW, int DF>
 __device__ __forceinline__ void mgx_tb_tile(const T *__restrict__ src, T *__restrict__ dst, const MgxGeom &g,
                                             const MgxSweepParams<T> &p, const MgxBox *__restrict__ bx, const int nb,
                                             const int ntx, const int tile, const int zc0, const int zc1, const int reduce,
-                                            u64 *__restrict__ res, T *__restrict__ lds, MgxBoxLds<T> *__restrict__ bl) {
+                                            u64 *__restrict__ res, T *__restrict__ lds, MgxBoxLds<T> *__restrict__ bl,
+                                            const int n_commit) {
   const int tx = tile % ntx, ty = tile / ntx;
   const int tx0 = 1 + tx * 128, ty0 = 1 + ty * TY;
   const int wave = threadIdx.x >> 6;
@@ -412,14 +412,14 @@ __device__ __forceinline__ void mgx_tb_tile(const T *__restrict__ src, T *__rest
   // (see FREE above) staged rows ty0-2NS .. ty0+TY-1+2NS and columns tx0 .. tx0+127 all interior
   const bool free_rows = BOXES == 0 && ty0 - 2 * NS >= 1 && ty0 + TY - 1 + 2 * NS <= g.n2 && tx0 + 127 <= g.n1;
   if (halo) {
-    if (p0) mgx_tb_body<T, NS, TY, BOXES, NW, DF, 1, true>(src, dst, g, p, bx, nb, tx0, ty0, zc0, zc1, reduce, res, lds, bl);
-    else mgx_tb_body<T, NS, TY, BOXES, NW, DF, 0, true>(src, dst, g, p, bx, nb, tx0, ty0, zc0, zc1, reduce, res, lds, bl);
+    if (p0) mgx_tb_body<T, NS, TY, BOXES, NW, DF, 1, true>(src, dst, g, p, bx, nb, tx0, ty0, zc0, zc1, reduce, res, lds, bl, n_commit);
+    else mgx_tb_body<T, NS, TY, BOXES, NW, DF, 0, true>(src, dst, g, p, bx, nb, tx0, ty0, zc0, zc1, reduce, res, lds, bl, n_commit);
   } else if (BOXES == 0 && free_rows) {
-    if (p0) mgx_tb_body<T, NS, TY, 0, NW, DF, 1, false, true>(src, dst, g, p, bx, nb, tx0, ty0, zc0, zc1, reduce, res, lds, bl);
-    else mgx_tb_body<T, NS, TY, 0, NW, DF, 0, false, true>(src, dst, g, p, bx, nb, tx0, ty0, zc0, zc1, reduce, res, lds, bl);
+    if (p0) mgx_tb_body<T, NS, TY, 0, NW, DF, 1, false, true>(src, dst, g, p, bx, nb, tx0, ty0, zc0, zc1, reduce, res, lds, bl, n_commit);
+    else mgx_tb_body<T, NS, TY, 0, NW, DF, 0, false, true>(src, dst, g, p, bx, nb, tx0, ty0, zc0, zc1, reduce, res, lds, bl, n_commit);
   } else {
-    if (p0) mgx_tb_body<T, NS, TY, BOXES, NW, DF, 1, false>(src, dst, g, p, bx, nb, tx0, ty0, zc0, zc1, reduce, res, lds, bl);
-    else mgx_tb_body<T, NS, TY, BOXES, NW, DF, 0, false>(src, dst, g, p, bx, nb, tx0, ty0, zc0, zc1, reduce, res, lds, bl);
+    if (p0) mgx_tb_body<T, NS, TY, BOXES, NW, DF, 1, false>(src, dst, g, p, bx, nb, tx0, ty0, zc0, zc1, reduce, res, lds, bl, n_commit);
+    else mgx_tb_body<T, NS, TY, BOXES, NW, DF, 0, false>(src, dst, g, p, bx, nb, tx0, ty0, zc0, zc1, reduce, res, lds, bl, n_commit);
   }
 }
 
@@ -432,18 +432,18 @@ template <typename T, int NS, int TY, int NW, int DF>
 __global__ __launch_bounds__((NW + 1) * 64) void k_tb_sweep(const T *__restrict__ src, T *__restrict__ dst, const MgxGeom g,
                                                             const MgxSweepParams<T> p, const MgxBox *__restrict__ bx,
                                                             const int nb, const int ntx, const int *__restrict__ tiles,
-                                                            const int n_box, const int n_const, const int reduce,
+                                                            const int n_commit, const int reduce,
                                                             u64 *__restrict__ res) {
   extern __shared__ __align__(16) unsigned char mgx_lds_raw[];
   T *lds = reinterpret_cast<T *>(mgx_lds_raw);
   MgxBoxLds<T> *bl = reinterpret_cast<MgxBoxLds<T> *>(mgx_lds_raw + mgx_tb_lds_field<T, NS, TY, NW>());
   const int b = blockIdx.x;
-  const int cls = b < n_box ? 2 : b < n_box + n_const ? 1 : 0;
-  const int tile = tiles[3 * b], zc0 = tiles[3 * b + 1], zc1 = tiles[3 * b + 2];
-  if (tile < 0) return;
-  if (cls == 2) mgx_tb_tile<T, NS, TY, 2, NW, DF>(src, dst, g, p, bx, nb, ntx, tile, zc0, zc1, reduce, res, lds, bl);
-  else if (cls == 1) mgx_tb_tile<T, NS, TY, 1, NW, DF>(src, dst, g, p, bx, nb, ntx, tile, zc0, zc1, reduce, res, lds, bl);
-  else mgx_tb_tile<T, NS, TY, 0, NW, DF>(src, dst, g, p, bx, nb, ntx, tile, zc0, zc1, reduce, res, lds, bl);
+  const int entry = tiles[3 * b], zc0 = tiles[3 * b + 1], zc1 = tiles[3 * b + 2];
+  if (entry < 0) return;
+  const int cls = entry >> MGX_TILE_CLASS_SHIFT, tile = entry & ((1 << MGX_TILE_CLASS_SHIFT) - 1);
+  if (cls == 2) mgx_tb_tile<T, NS, TY, 2, NW, DF>(src, dst, g, p, bx, nb, ntx, tile, zc0, zc1, reduce, res, lds, bl, n_commit);
+  else if (cls == 1) mgx_tb_tile<T, NS, TY, 1, NW, DF>(src, dst, g, p, bx, nb, ntx, tile, zc0, zc1, reduce, res, lds, bl, n_commit);
+  else mgx_tb_tile<T, NS, TY, 0, NW, DF>(src, dst, g, p, bx, nb, ntx, tile, zc0, zc1, reduce, res, lds, bl, n_commit);
 }
 
 template <typename T, int NS, int TY, int NW, int DF>
@@ -463,6 +463,6 @@ static int mgx_tb_launch_cfg(const MgxFusedPlan &pl, const T *src, T *dst, const
   const int total = tl.n_box + tl.n_const + tl.n_fast;
   if (total > 0)
     hipLaunchKernelGGL((k_tb_sweep<T, NS, TY, NW, DF>), dim3((unsigned)total), dim3((NW + 1) * 64), lds, st, src, dst, g, p, bx,
-                       nb, pl.ntx, pl.d_tiles + 3 * tl.offset, tl.n_box, tl.n_const, reduce, res);
+                       nb, pl.ntx, pl.d_tiles + 3 * tl.offset, (reduce & 3) ? tl.n_real : 0, reduce, res);
   return 0;
 }

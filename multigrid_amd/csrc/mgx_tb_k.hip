@@ -13,11 +13,11 @@ static int tb_df() {
 
 int mgx_tb2_launch_f64(const MgxFusedPlan &pl, const double *src, double *dst, const MgxGeom &g,
                        const MgxSweepParams<double> &p, const MgxBox *bx, int nb, int reduce, u64 *res, hipStream_t st) {
-  if (tb_df() == 1) return mgx_tb_launch_cfg<double, 2, 22, 6, 1>(pl, src, dst, g, p, bx, nb, reduce, res, st);
-  return mgx_tb_launch_cfg<double, 2, 22, 6, 2>(pl, src, dst, g, p, bx, nb, reduce, res, st);
+  if (tb_df() == 1) return mgx_tb_launch_cfg<double, 2, MGX_TB_TY, MGX_TB_NW, 1>(pl, src, dst, g, p, bx, nb, reduce, res, st);
+  return mgx_tb_launch_cfg<double, 2, MGX_TB_TY, MGX_TB_NW, 2>(pl, src, dst, g, p, bx, nb, reduce, res, st);
 }
 int mgx_tb2_launch_f32(const MgxFusedPlan &pl, const float *src, float *dst, const MgxGeom &g,
                        const MgxSweepParams<float> &p, const MgxBox *bx, int nb, int reduce, u64 *res, hipStream_t st) {
-  if (tb_df() == 1) return mgx_tb_launch_cfg<float, 2, 22, 6, 1>(pl, src, dst, g, p, bx, nb, reduce, res, st);
-  return mgx_tb_launch_cfg<float, 2, 22, 6, 2>(pl, src, dst, g, p, bx, nb, reduce, res, st);
+  if (tb_df() == 1) return mgx_tb_launch_cfg<float, 2, MGX_TB_TY, MGX_TB_NW, 1>(pl, src, dst, g, p, bx, nb, reduce, res, st);
+  return mgx_tb_launch_cfg<float, 2, MGX_TB_TY, MGX_TB_NW, 2>(pl, src, dst, g, p, bx, nb, reduce, res, st);
 }

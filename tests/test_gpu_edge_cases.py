@@ -123,6 +123,9 @@ def test_error_codes(ctx):
         with pytest.raises(lib.MgxError) as e:
             lv.set_boxes([(1, 2, 1, 2, 1, 2)], [0.0], [-1.0], [0])     # rho < 0 (t_mg.f90:352)
         assert e.value.code == -1
+        with pytest.raises(lib.MgxError) as e:
+            lv.set_boxes([(1, 2, 1, 2, 1, 2)], [2.0 ** 19], [1.0], [1])   # beyond the range of the exact sum of |V|
+        assert e.value.code == -5 and "2^19" in str(e.value)
         with pytest.raises(lib.MgxError):
             lv.half_sweep(2, 1, 8, 0)
         with pytest.raises(lib.MgxError):
