@@ -56,8 +56,12 @@ enum { MGX_RED_ERR = 1, MGX_RED_SUM = 2 };
 enum { MGX_PART_EDGE = 1, MGX_PART_INNER = 2 };
 /* sweep kernel selection (results are bit-identical; for tests and benchmarking): AUTO = the fused kernel, with two
  * sweeps per pass on the levels where that pays; TWO_PASS = one colour per launch, in place; FUSED = black and red
- * in one pass, one sweep per pass everywhere; PAIR = as FUSED, two sweeps per pass wherever that kernel applies */
-enum { MGX_KERNEL_AUTO = 0, MGX_KERNEL_TWO_PASS = 1, MGX_KERNEL_FUSED = 2, MGX_KERNEL_PAIR = 3 };
+ * in one pass, one sweep per pass everywhere; PAIR = as FUSED, two sweeps per pass wherever that kernel applies.
+ * LEX is NOT one of them: it sweeps in the reference's own order (gs, m_gs_CDS.F90:317-345: in place, z outermost, x
+ * innermost; on the device hyperplane by hyperplane, one launch each), so its results are those of the reference run
+ * on one thread, bit for bit, at any over-relaxation; many times slower than the red-black kernels; undivided levels;
+ * mgx_level_sweep only (mgx_level_solve and mgx_level_sweep_part return MGX_ESTATE: loop on the host). */
+enum { MGX_KERNEL_AUTO = 0, MGX_KERNEL_TWO_PASS = 1, MGX_KERNEL_FUSED = 2, MGX_KERNEL_PAIR = 3, MGX_KERNEL_LEX = 4 };
 
 const char *mgx_last_error(void);
 const char *mgx_version(void);
@@ -68,7 +72,8 @@ const char *mgx_version(void);
 int mgx_ctx_create(int device, void *stream, mgx_ctx **out);
 int mgx_ctx_destroy(mgx_ctx *ctx);
 int mgx_ctx_sync(mgx_ctx *ctx);                                   /* [sync] */
-int mgx_ctx_set_kernel(mgx_ctx *ctx, int which);                   /* MGX_KERNEL_* */
+int mgx_ctx_set_kernel(mgx_ctx *ctx, int which);                   /* MGX_KERNEL_*; a new context starts with AUTO, or
+                                                                      with the value of the environment variable MGX_KERNEL */
 /* the device and the hipStream_t a context enqueues on (for hosts that order their own transfers or events against
  * the library's kernels, e.g. the halo exchange of mgx_rccl.h); either pointer may be NULL */
 int mgx_ctx_info(mgx_ctx *ctx, int *device, void **stream);

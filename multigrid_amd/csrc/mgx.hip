@@ -182,6 +182,9 @@ extern "C" int mgx_ctx_create(int device, void *stream, mgx_ctx **out) {
   if (const char *e = getenv("MGX_FUSED_ORDER")) mgx_fused_order = atoi(e);
   if (const char *e = getenv("MGX_FUSED_BOXCUT")) mgx_fused_boxcut = atoi(e);
   if (const char *e = getenv("MGX_PAIR_PASS")) mgx_pair_pass = atoi(e);   // 0 off, 1 on every level the kernel takes
+  // initial kernel selection (MGX_KERNEL_*), for hosts that have no call of mgx_ctx_set_kernel of their own:
+  // MGX_KERNEL=4 runs the reference's program over this library in the reference's sweep order
+  if (const char *e = getenv("MGX_KERNEL")) { const int k = atoi(e); if (k >= MGX_KERNEL_AUTO && k <= MGX_KERNEL_LEX) c->kernel = k; }
   if (stream) {
     c->stream = (hipStream_t)stream;
   } else {
@@ -371,7 +374,7 @@ extern "C" int mgx_level_context(mgx_level *lv, mgx_ctx **ctx) {
 
 extern "C" int mgx_ctx_set_kernel(mgx_ctx *ctx, int which) {
   if (!ctx) return fail(MGX_EINVAL, "mgx_ctx_set_kernel: ctx is NULL");
-  if (which < MGX_KERNEL_AUTO || which > MGX_KERNEL_PAIR) return fail(MGX_EINVAL, "mgx_ctx_set_kernel: %d", which);
+  if (which < MGX_KERNEL_AUTO || which > MGX_KERNEL_LEX) return fail(MGX_EINVAL, "mgx_ctx_set_kernel: %d", which);
   ctx->kernel = which;
   return MGX_OK;
 }
@@ -648,10 +651,40 @@ static bool pair_pass_wanted(const mgx_level *lv) {
   return pieces >= 512;
 }
 
+// one sweep in the reference's order (k_lex_plane): a launch per hyperplane x + y + z = d, d = 3 .. n1 + n2 + n3; the
+// planes that hold a cell of hyperplane d are d - n1 - n2 .. d - 2, so only the (x, y) blocks that can hold one are
+// launched.  The reductions follow the cleared-replicas protocol: max (vv - V)^2 from the sweep, the sum from a pass of
+// k_abs_sum behind it.
+template <typename T>
+static int lex_sweep(mgx_level *lv, int reduce) {
+  const MgxGeom &g = lv->g;
+  hipStream_t st = C(lv)->stream;
+  if (reduce) TRY(reset_result(lv));
+  const MgxSweepParams<T> p = make_params<T>(lv);
+  const dim3 grid((g.n1 + 63) / 64, (g.n2 + 3) / 4);
+  for (int d = 3; d <= g.n1 + g.n2 + g.n3; ++d)
+    hipLaunchKernelGGL((k_lex_plane<T>), grid, dim3(256), 0, st, (T *)lv->buf[lv->cur], g, p, lv->d_boxes, lv->nbox, d,
+                       reduce & MGX_RED_ERR, lv->d_res);
+  HIP_TRY(hipGetLastError());
+  if (reduce & MGX_RED_SUM) {
+    const long long rows = (long long)g.n2 * g.n3;
+    const int blocks = (int)std::max(1LL, std::min(4096LL, (rows + 3) / 4));
+    hipLaunchKernelGGL((k_abs_sum<T>), dim3(blocks), dim3(256), 0, st, (const T *)lv->buf[lv->cur], g, 1, g.n3, lv->d_res);
+    HIP_TRY(hipGetLastError());
+  }
+  if (reduce) lv->slots_dirty = true;
+  return MGX_OK;
+}
+
 template <typename T>
 static int do_sweeps(mgx_level *lv, int nsweeps, int reduce) {
   const MgxGeom &g = lv->g;
   int which = C(lv)->kernel;
+  if (which == MGX_KERNEL_LEX) {
+    if (g.n3 != g.n3g) return fail(MGX_ESTATE, "mgx_level_sweep: the reference's order needs the undivided level");
+    for (int s = 0; s < nsweeps; ++s) TRY(lex_sweep<T>(lv, s == nsweeps - 1 ? reduce : 0));
+    return MGX_OK;
+  }
   if (which == MGX_KERNEL_AUTO) which = mgx_fused_supported<T>(g, lv->nbox) ? MGX_KERNEL_FUSED : MGX_KERNEL_TWO_PASS;
   if (which == MGX_KERNEL_PAIR) which = MGX_KERNEL_FUSED;
   if (which == MGX_KERNEL_FUSED && !mgx_fused_supported<T>(g, lv->nbox))
@@ -721,7 +754,7 @@ extern "C" int mgx_level_sweep(mgx_level *lv, int nsweeps, int reduce) {
 template <typename T>
 static int do_sweep_part(mgx_level *lv, int part, int reduce) {
   const MgxGeom &g = lv->g;
-  if (!mgx_fused_supported<T>(g, lv->nbox) || C(lv)->kernel == MGX_KERNEL_TWO_PASS)
+  if (!mgx_fused_supported<T>(g, lv->nbox) || C(lv)->kernel == MGX_KERNEL_TWO_PASS || C(lv)->kernel == MGX_KERNEL_LEX)
     return fail(MGX_ESTATE, "mgx_level_sweep_part: needs the fused kernel (at most %d boxes, kernel not forced to two-pass)",
                 MGX_MAX_FUSED_BOXES);
   if (part == MGX_PART_EDGE) {
@@ -835,7 +868,7 @@ extern "C" int mgx_level_solve(mgx_level *lv, double tol_level, int64_t count_no
   NOT_WHILE_CAPTURING(C(lv), "mgx_level_solve");
   if (lv->g.n3 != lv->g.n3g) return fail(MGX_ESTATE, "mgx_level_solve: a slab needs a halo exchange between sweeps: loop on the host");
   const bool ok = lv->elem == 4 ? mgx_fused_supported<float>(lv->g, lv->nbox) : mgx_fused_supported<double>(lv->g, lv->nbox);
-  if (!ok || C(lv)->kernel == MGX_KERNEL_TWO_PASS)
+  if (!ok || C(lv)->kernel == MGX_KERNEL_TWO_PASS || C(lv)->kernel == MGX_KERNEL_LEX)
     return fail(MGX_ESTATE, "mgx_level_solve: needs the fused kernel (at most %d boxes, kernel not forced to two-pass): loop on the host", MGX_MAX_FUSED_BOXES);
   TRY(set_device(C(lv)));
   TRY(materialize(lv));

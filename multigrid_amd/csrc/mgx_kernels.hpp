@@ -326,6 +326,33 @@ __global__ __launch_bounds__(256) void k_half_sweep(T *__restrict__ V, const Mgx
 }
 
 // ------------------------------------------------------------------------------------------------
+// The reference's own order: gs (m_gs_CDS.F90:317-345) updates the cells in place with z outermost and x innermost,
+// so a cell sees the new values of x-1, y-1, z-1 and the old ones of x+1, y+1, z+1.  Every order in which those three
+// come first gives the same bits; the cells of a hyperplane x + y + z = d depend on hyperplane d - 1 only, so one
+// launch per hyperplane reproduces the one-thread reference sweep exactly, whatever the over-relaxation.  Thread =
+// (x, y), z = d - x - y.  Undivided levels only.  The accesses of a wave lie in 64 different rows: this is the order
+// for results identical to the reference's, not the fast one.
+template <typename T>
+__global__ __launch_bounds__(256) void k_lex_plane(T *__restrict__ V, const MgxGeom g, const MgxSweepParams<T> p,
+                                                   const MgxBox *__restrict__ bx, const int nb, const int d,
+                                                   const int reduce, u64 *__restrict__ res) {
+  const int x = blockIdx.x * 64 + (threadIdx.x & 63) + 1;
+  const int y = blockIdx.y * 4 + (threadIdx.x >> 6) + 1;
+  const int z = d - x - y;
+  T err = (T)0;
+  if (x <= g.n1 && y <= g.n2 && z >= 1 && z <= g.n3) {
+    const long long c = g.idx(x, y, z);
+    const T vc = V[c];
+    const T vv = mgx_cell_new<T>(vc, V[c - 1], V[c + 1], V[c - g.px], V[c + g.px], V[c - g.pz], V[c + g.pz], nb ? 3 : 0,
+                                 bx, nb, x, y, z, p);
+    const T dv = vv - vc;
+    err = dv * dv;
+    V[c] = vv;
+  }
+  if (reduce & 1) mgx_block_commit<4>((double)err, 0ull, 0ull, 0u, 1, res);
+}
+
+// ------------------------------------------------------------------------------------------------
 // grid_sum (t_mg.f90:794-814) over local planes [zlo,zhi]; block = 256 threads, one row per wave step
 
 template <typename T>

@@ -32,7 +32,8 @@ def divergence_hint(sor: float) -> str:
     return (f"  The level runs sor = {sor:g}.  In red-black order the reference's cycle (restriction and prolongation "
             f"overwrite the levels, m_gs_CDS.F90:220-294) is stable only up to sor = 1.70 (periodic z) to 1.76 (Dirichlet "
             f"z), whereas the reference's lexicographic sweep tolerates its parser default of 1.8 (m_mg_io.F90:87): "
-            f"put `sor 1.7` into the layers block.")
+            f"put `sor 1.7` into the layers block, or sweep in the reference's order (`--reference-order`, "
+            f"mgx_ctx_set_kernel(ctx, MGX_KERNEL_LEX): slower, the reference's results bit for bit).")
 
 
 class Solver:

@@ -9,7 +9,8 @@ module mgx_c
   integer(c_int), parameter :: MGX_BC_PERIODIC = 1, MGX_BC_DIRICHLET = 2, MGX_BC_NEUMANN = 3   ! t_bc.f90:13-15
   integer(c_int), parameter :: MGX_RED_ERR = 1, MGX_RED_SUM = 2
   integer(c_int), parameter :: MGX_PART_EDGE = 1, MGX_PART_INNER = 2
-  integer(c_int), parameter :: MGX_KERNEL_AUTO = 0, MGX_KERNEL_TWO_PASS = 1, MGX_KERNEL_FUSED = 2, MGX_KERNEL_PAIR = 3
+  integer(c_int), parameter :: MGX_KERNEL_AUTO = 0, MGX_KERNEL_TWO_PASS = 1, MGX_KERNEL_FUSED = 2, MGX_KERNEL_PAIR = 3, &
+       MGX_KERNEL_LEX = 4   ! the reference's own sweep order (slow; results of the reference on one thread)
   integer(c_int), parameter :: MGX_OK = 0, MGX_EINVAL = -1, MGX_EHIP = -2, MGX_ENOMEM = -3, MGX_ESTATE = -4, MGX_ELIMIT = -5
 
   interface

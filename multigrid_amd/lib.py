@@ -16,7 +16,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.environ.get("MGX_LIB") or os.path.join(_HERE, "libmgx.so")
 
 RED_ERR, RED_SUM = 1, 2
-KERNEL_AUTO, KERNEL_TWO_PASS, KERNEL_FUSED = 0, 1, 2
+KERNEL_AUTO, KERNEL_TWO_PASS, KERNEL_FUSED, KERNEL_PAIR = 0, 1, 2, 3
+KERNEL_LEX = 4      # the reference's own sweep order (results of the reference on one thread, bit for bit; slow)
 INTERP_FULL, INTERP_HALF = 1, 2
 BC_PERIODIC, BC_DIRICHLET, BC_NEUMANN = 1, 2, 3
 PART_EDGE, PART_INNER = 1, 2

@@ -28,6 +28,28 @@ def dev_level(ctx, L, dtype, layer=1):
     return lv
 
 
+@pytest.mark.parametrize("prec", ["f32", "f64"])
+@pytest.mark.parametrize("name", SWEEPS)
+def test_reference_order_sweep_equals_the_reference(ctx, name, prec):
+    """MGX_KERNEL_LEX against the fields the compiled reference left after each gs_step (no oracle in between)"""
+    from multigrid_amd import lib
+    g = load(f"{name}_{prec}")
+    L = level_of(g)
+    ctx.set_kernel(lib.KERNEL_LEX)
+    try:
+        lv = dev_level(ctx, L, g["V0"].dtype)
+        lv.upload(g["V0"].copy())
+        for k in range(int(g["k"])):
+            lv.sweep(1, lib.RED_ERR | lib.RED_SUM)
+            de2, ds, _ = lv.result()
+            assert bits_equal(lv.download(), g["V"][k]), f"{name} {prec} sweep {k}"
+            assert np.sqrt(g["V0"].dtype.type(de2)) == g["V0"].dtype.type(g["err"][k])       # grid%err = sqrt(err), m_gs_CDS.F90:313
+            assert abs(ds - float(g["sum"][k])) <= (1e-12 if prec == "f64" else 2e-4) * abs(float(g["sum"][k]))
+        lv.close()
+    finally:
+        ctx.set_kernel(0)
+
+
 @pytest.mark.parametrize("kernel", [1, 2])
 @pytest.mark.parametrize("prec", ["f32", "f64"])
 @pytest.mark.parametrize("name", SWEEPS)

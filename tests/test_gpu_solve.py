@@ -165,3 +165,46 @@ def test_recorded_cycle_equals_call_by_call(name, prec):
     for f in ("layer", "kind", "itt", "tol", "sum", "err"):
         assert np.array_equal(h0[f], h1[f]), f
     assert bits_equal(W0, W1)
+
+
+# ---- the reference's own sweep order on the GPU (MGX_KERNEL_LEX): results identical to the compiled reference ----
+
+@pytest.mark.parametrize("prec", ["f32", "f64"])
+@pytest.mark.parametrize("name", SOLVES)
+def test_reference_order_solve_equals_the_reference(name, prec):
+    """the golden field is what the reference's own `mg` program wrote (one thread) for this input, sor 1.8 included:
+    the hyperplane sweep reproduces it bit for bit (the exact sum trips every convergence test where the
+    reference's sequential sum does on these inputs)"""
+    from multigrid_amd import lib
+    g = load(f"{name}_{prec}")
+    IO = mgio.MgIO(text=str(g["input"]))
+    top = mgio.iomg_read(IO, dtype=DT[prec])
+    method = mgio.read_method(IO)
+    s = cycle.Solver(top)
+    try:
+        s.ctx.set_kernel(lib.KERNEL_LEX)
+        s.mg_gs_cds(method)
+        W = top.dev.download()
+        assert bits_equal(np.ascontiguousarray(W[1:-1]), np.ascontiguousarray(g["V"]))
+        if method == 1:
+            assert {i + 1: l.itt for i, l in enumerate(top.levels())} == {int(l): int(c) for l, c in g["bu_counts"]}
+    finally:
+        s.close()
+
+
+def test_reference_order_test6_fp64():
+    """config 1 (test/test6.input) in the reference's order: its sweep counts 126/9/4 and its field"""
+    from multigrid_amd import lib
+    g = load("test6_f64")
+    IO = mgio.MgIO(text=str(g["input"]))
+    top = mgio.iomg_read(IO, dtype=np.float64)
+    s = cycle.Solver(top)
+    try:
+        s.ctx.set_kernel(lib.KERNEL_LEX)
+        s.mg_gs_cds(mgio.read_method(IO))
+        assert [l.itt for l in top.levels()] == [int(c) for _, c in sorted(g["bu_counts"].tolist())]
+        sub = int(g["subsample"])
+        W = top.dev.download()
+        assert bits_equal(np.ascontiguousarray(W[1:-1][::sub, ::sub, ::sub]), np.ascontiguousarray(g["V"]))
+    finally:
+        s.close()
