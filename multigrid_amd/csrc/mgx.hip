@@ -62,6 +62,7 @@ extern "C" const char *mgx_version(void) { return "mgx 0.1 (gfx950)"; }
 static __device__ __align__(256) u64 scratch[MGX_NOALLOC_MAX_BLOCKS * MGX_NOALLOC_REC];   // 512 KiB
 static u64 *g_scratch_ptr[MGX_MAX_DEVICES] = {nullptr};
 
+static int mgx_lex_tiled = 1;    // the reference-order sweep by tile hyperplanes (1) or by cell hyperplanes (0)
 static int mgx_pair_pass = -1;   // 0: never two sweeps per pass, 1: wherever the kernel applies, -1: where it pays (default)
 
 // ------------------------------------------------------------------------------------------------
@@ -181,6 +182,7 @@ extern "C" int mgx_ctx_create(int device, void *stream, mgx_ctx **out) {
   if (const char *e = getenv("MGX_FUSED_TAIL")) mgx_fused_tail = atoi(e);
   if (const char *e = getenv("MGX_FUSED_ORDER")) mgx_fused_order = atoi(e);
   if (const char *e = getenv("MGX_FUSED_BOXCUT")) mgx_fused_boxcut = atoi(e);
+  if (const char *e = getenv("MGX_LEX_TILED")) mgx_lex_tiled = atoi(e);
   if (const char *e = getenv("MGX_PAIR_PASS")) mgx_pair_pass = atoi(e);   // 0 off, 1 on every level the kernel takes
   // initial kernel selection (MGX_KERNEL_*), for hosts that have no call of mgx_ctx_set_kernel of their own:
   // MGX_KERNEL=4 runs the reference's program over this library in the reference's sweep order
@@ -576,7 +578,14 @@ static int do_setup(mgx_level *lv, int init) {
   bool any_const = false;
   for (const MgxBox &b : lv->boxes) any_const |= b.constant != 0;
   if (any_const) {
-    dim3 grid(64, lv->nbox);
+    // blocks per box: enough for the largest box of the level to take a few cells per thread on every compute unit
+    long long most = 1;
+    for (const MgxBox &b : lv->boxes)
+      if (b.constant)
+        most = std::max(most, (long long)std::max(0, std::min(b.hi[0], g.n1) - std::max(b.lo[0], 1) + 1) *
+                                  std::max(0, std::min(b.hi[1], g.n2) - std::max(b.lo[1], 1) + 1) *
+                                  std::max(0, std::min(b.hi[2], g.n3 + g.z0) - std::max(b.lo[2], 1 + g.z0) + 1));
+    dim3 grid((unsigned)std::max(1LL, std::min(1024LL, (most + 1023) / 1024)), lv->nbox);
     hipLaunchKernelGGL((k_box_imprint<T>), grid, dim3(256), 0, st, V, g, lv->d_boxes, lv->nbox);
   }
   TRY(do_faces<T>(lv));
@@ -661,10 +670,20 @@ static int lex_sweep(mgx_level *lv, int reduce) {
   hipStream_t st = C(lv)->stream;
   if (reduce) TRY(reset_result(lv));
   const MgxSweepParams<T> p = make_params<T>(lv);
-  const dim3 grid((g.n1 + 63) / 64, (g.n2 + 3) / 4);
-  for (int d = 3; d <= g.n1 + g.n2 + g.n3; ++d)
-    hipLaunchKernelGGL((k_lex_plane<T>), grid, dim3(256), 0, st, (T *)lv->buf[lv->cur], g, p, lv->d_boxes, lv->nbox, d,
-                       reduce & MGX_RED_ERR, lv->d_res);
+  if (mgx_lex_tiled) {      // tile hyperplanes (k_lex_tile); MGX_LEX_TILED=0 selects the cell hyperplanes (k_lex_plane)
+    const int ntx = (g.n1 + MGX_LEX_TX - 1) / MGX_LEX_TX, nty = (g.n2 + MGX_LEX_TY - 1) / MGX_LEX_TY,
+              ntz = (g.n3 + MGX_LEX_TZ - 1) / MGX_LEX_TZ;
+    for (int D = 0; D <= ntx + nty + ntz - 3; ++D) {
+      // tiles (I, J, D - I - J) with 0 <= D - I - J < ntz: the rows J of the (I, J) grid that can hold one
+      hipLaunchKernelGGL((k_lex_tile<T>), dim3(ntx, nty), dim3(64), 0, st, (T *)lv->buf[lv->cur], g, p, lv->d_boxes,
+                         lv->nbox, D, reduce & MGX_RED_ERR, lv->d_res);
+    }
+  } else {
+    const dim3 grid((g.n1 + 63) / 64, (g.n2 + 3) / 4);
+    for (int d = 3; d <= g.n1 + g.n2 + g.n3; ++d)
+      hipLaunchKernelGGL((k_lex_plane<T>), grid, dim3(256), 0, st, (T *)lv->buf[lv->cur], g, p, lv->d_boxes, lv->nbox, d,
+                         reduce & MGX_RED_ERR, lv->d_res);
+  }
   HIP_TRY(hipGetLastError());
   if (reduce & MGX_RED_SUM) {
     const long long rows = (long long)g.n2 * g.n3;
@@ -1198,7 +1217,10 @@ static int launch_prolong(bool half, mgx_level *src, mgx_level *dst, const MgxTr
   const T *s = (const T *)src->buf[src->cur];
   T *d = (T *)dst->buf[dst->cur];
   const int2 *rx = (const int2 *)t->d_tab, *ry = (const int2 *)(t->d_tab + t->off_y), *rz = (const int2 *)(t->d_tab + t->off_z);
-  if (half) hipLaunchKernelGGL((k_prolong<T, true, ZCH>), grid, dim3(256), 0, st, s, gs, d, dst->g, rx, ry, rz, t->cz_lo, t->cz_hi);
+  if (dst->g.n1 == 2 * gs.n1 && gs.n1 >= 2) {    // exactly halved in x: aligned 16-byte stores (k_prolong_xhalved)
+    if (half) hipLaunchKernelGGL((k_prolong_xhalved<T, true, ZCH>), grid, dim3(256), 0, st, s, gs, d, dst->g, ry, rz, t->cz_lo, t->cz_hi);
+    else hipLaunchKernelGGL((k_prolong_xhalved<T, false, ZCH>), grid, dim3(256), 0, st, s, gs, d, dst->g, ry, rz, t->cz_lo, t->cz_hi);
+  } else if (half) hipLaunchKernelGGL((k_prolong<T, true, ZCH>), grid, dim3(256), 0, st, s, gs, d, dst->g, rx, ry, rz, t->cz_lo, t->cz_hi);
   else hipLaunchKernelGGL((k_prolong<T, false, ZCH>), grid, dim3(256), 0, st, s, gs, d, dst->g, rx, ry, rz, t->cz_lo, t->cz_hi);
   HIP_TRY(hipGetLastError());
   return MGX_OK;

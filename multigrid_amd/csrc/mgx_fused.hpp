@@ -70,26 +70,7 @@ struct MgxBoxLds {           // per-block copy of what the box logic needs
   uint4 yq[64];              // Y sets of rows y-1, y, y+1 around staged row r (rows past the tile: empty)
 };
 
-#define MGX_CODE_CONST 128u     // the cell lies in a constant box: val returns V itself (m_gs_CDS.F90:726-727)
-#define MGX_CODE_GENERAL 256u   // neighbours in two boxes with rho != 1, or in one without a table
 template <int R> struct MgxCodes { unsigned c[R]; };   // per pair: low half = black cell of plane k, high half = red cell of plane k-1
-
-// code of one cell from the sets of its own position and of its neighbours' positions
-__device__ inline unsigned mgx_cell_code(const unsigned X0, const unsigned Xm, const unsigned Xp, const uint4 ys,
-                                         const unsigned zl, const unsigned zc, const unsigned zh, const unsigned cmask,
-                                         const unsigned rmask, const unsigned tb0, const unsigned tb1) {
-  const unsigned c00 = ys.y & zc;
-  const unsigned sxm = Xm & c00, sxp = Xp & c00, sym = X0 & ys.x & zc, syp = X0 & ys.z & zc, szm = X0 & ys.y & zl,
-                 szp = X0 & ys.y & zh;
-  // first containing box decides rho (t_mg.f90:670-687); lowest set bit = first box; keep it only if rho != 1
-  const unsigned rxm = sxm & (0u - sxm) & rmask, rxp = sxp & (0u - sxp) & rmask, rym = sym & (0u - sym) & rmask,
-                 ryp = syp & (0u - syp) & rmask, rzm = szm & (0u - szm) & rmask, rzp = szp & (0u - szp) & rmask;
-  const unsigned R = rxm | rxp | rym | ryp | rzm | rzp;
-  const bool general = (R & (R - 1u)) != 0u || (R & ~(tb0 | tb1)) != 0u;
-  const unsigned m = (rxm ? 1u : 0u) | (rxp ? 2u : 0u) | (rym ? 4u : 0u) | (ryp ? 8u : 0u) | (rzm ? 16u : 0u) |
-                     (rzp ? 32u : 0u);
-  return (general ? MGX_CODE_GENERAL : (((R & tb1) ? 64u : 0u) | m)) | ((X0 & c00 & cmask) ? MGX_CODE_CONST : 0u);
-}
 
 // codes of the R pairs of a lane (staged rows rr[]) for one step: black cells on the plane with Z sets (zm, z0, zp)
 // around it, red cells one plane below (zmm, zm, z0).  qsel bit j = position of the cell in pair j.

@@ -288,6 +288,30 @@ __device__ inline T mgx_cell_new(const T vc, const T vxm, const T vxp, const T v
 }
 
 // ------------------------------------------------------------------------------------------------
+// box predicates as bit sets over at most 32 boxes: in_box(b, x, y, z) = X_b(x) & Y_b(y) & Z_b(z)
+
+#define MGX_CODE_CONST 128u     // the cell lies in a constant box: val returns V itself (m_gs_CDS.F90:726-727)
+#define MGX_CODE_GENERAL 256u   // neighbours in two boxes with rho != 1, or in one without a table
+
+// code of one cell from the sets of its own position and of its neighbours' positions
+__device__ inline unsigned mgx_cell_code(const unsigned X0, const unsigned Xm, const unsigned Xp, const uint4 ys,
+                                         const unsigned zl, const unsigned zc, const unsigned zh, const unsigned cmask,
+                                         const unsigned rmask, const unsigned tb0, const unsigned tb1) {
+  const unsigned c00 = ys.y & zc;
+  const unsigned sxm = Xm & c00, sxp = Xp & c00, sym = X0 & ys.x & zc, syp = X0 & ys.z & zc, szm = X0 & ys.y & zl,
+                 szp = X0 & ys.y & zh;
+  // first containing box decides rho (t_mg.f90:670-687); lowest set bit = first box; keep it only if rho != 1
+  const unsigned rxm = sxm & (0u - sxm) & rmask, rxp = sxp & (0u - sxp) & rmask, rym = sym & (0u - sym) & rmask,
+                 ryp = syp & (0u - syp) & rmask, rzm = szm & (0u - szm) & rmask, rzp = szp & (0u - szp) & rmask;
+  const unsigned R = rxm | rxp | rym | ryp | rzm | rzp;
+  const bool general = (R & (R - 1u)) != 0u || (R & ~(tb0 | tb1)) != 0u;
+  const unsigned m = (rxm ? 1u : 0u) | (rxp ? 2u : 0u) | (rym ? 4u : 0u) | (ryp ? 8u : 0u) | (rzm ? 16u : 0u) |
+                     (rzp ? 32u : 0u);
+  return (general ? MGX_CODE_GENERAL : (((R & tb1) ? 64u : 0u) | m)) | ((X0 & c00 & cmask) ? MGX_CODE_CONST : 0u);
+}
+
+
+// ------------------------------------------------------------------------------------------------
 // two-pass smoother: one colour, in place.  Block = 64 x-pairs * 4 rows, marching ZB planes.
 
 template <typename T, int ZB>
@@ -350,6 +374,145 @@ __global__ __launch_bounds__(256) void k_lex_plane(T *__restrict__ V, const MgxG
     V[c] = vv;
   }
   if (reduce & 1) mgx_block_commit<4>((double)err, 0ull, 0ull, 0u, 1, res);
+}
+
+// The reference's order by tiles.  A tile of MGX_LEX_TX x MGX_LEX_TY x MGX_LEX_TZ cells needs the new values of the
+// tiles before it in x, y and z and the old ones of the tiles behind it, so the tiles of a hyperplane I + J + K = D of
+// the tile grid are independent: one launch per tile hyperplane, one wave per tile.  The wave stages the tile and its
+// shell in LDS (the faces towards x-1, y-1, z-1 hold what earlier launches wrote, the others the old values), sweeps
+// it by the hyperplanes i + j + k = m of the tile (lane = (j, k), i = m - j - k: at most one cell per lane and step,
+// every operand in LDS as the order demands) and writes the tile back.  Same bits as k_lex_plane, with rows of
+// MGX_LEX_TX cells moved at a time and (TX + TY + TZ - 2) steps per launch instead of one.
+#define MGX_LEX_TX 32
+#define MGX_LEX_TY 8
+#define MGX_LEX_TZ 8
+template <typename T>
+struct MgxLexBoxLds {        // what a tile that boxes reach keeps next to its cells (at most 32 boxes)
+  unsigned xs[MGX_LEX_TX + 2], ys[MGX_LEX_TY + 2], zs[MGX_LEX_TZ + 2];   // boxes whose range holds x0-1+l, y0-1+l, z0-1+l
+  // weights of a cell whose neighbours x-,x+,y-,y+,z-,z+ (bit i of m) have table box t (the first or the second box
+  // with rho != 1) as their first box, the others rho = 1, with the reference's arithmetic (m_gs_CDS.F90:729-735)
+  T wtab[2][64][6];
+  unsigned short code[MGX_LEX_TZ * MGX_LEX_TY * MGX_LEX_TX];            // mgx_cell_code of every cell of the tile
+};
+
+template <typename T>
+__global__ __launch_bounds__(64) void k_lex_tile(T *__restrict__ V, const MgxGeom g, const MgxSweepParams<T> p,
+                                                 const MgxBox *__restrict__ bx, const int nb, const int D,
+                                                 const int reduce, u64 *__restrict__ res) {
+  constexpr int TX = MGX_LEX_TX, TY = MGX_LEX_TY, TZ = MGX_LEX_TZ;
+  constexpr int PX = TX + 3, PY = (TY + 2) * PX;          // pitches of the staged tile (row, plane), in elements
+  __shared__ T t[(TZ + 2) * PY];
+  __shared__ MgxBox sbx[32];                               // the box table next to the tile: a step waits for LDS, not for memory
+  __shared__ MgxLexBoxLds<T> bl;
+  const int I = blockIdx.x, J = blockIdx.y, K = D - I - J;
+  const int x0 = I * TX + 1, y0 = J * TY + 1, z0 = K * TZ + 1;     // first cell of the tile
+  T err = (T)0;
+  const bool live = K >= 0 && z0 <= g.n3;                 // (uniform) this block's tile lies on the hyperplane
+  if (live) {
+    const int nx = min(TX, g.n1 - x0 + 1), ny = min(TY, g.n2 - y0 + 1), nz = min(TZ, g.n3 - z0 + 1);
+    const int lane = threadIdx.x;
+    if (nb <= 32 && lane < nb) sbx[lane] = bx[lane];
+    const MgxBox *const boxes = nb <= 32 ? sbx : bx;
+    // element e of the shell-grown tile, rows of TX + 2: loads in batches, so that a batch is in flight at a time
+    // instead of one load (edges and corners are not read: loaded anyway)
+    const T *const org = V + g.idx(x0 - 1, y0 - 1, z0 - 1);
+    constexpr int RW = TX + 2, BATCH = 9, NB = ((TY + 2) * (TZ + 2) * RW + 64 * BATCH - 1) / (64 * BATCH);
+#pragma unroll 1
+    for (int b = 0; b < NB; ++b) {
+      T tmp[BATCH];
+      int at[BATCH];
+#pragma unroll
+      for (int u = 0; u < BATCH; ++u) {
+        const int e = (b * BATCH + u) * 64 + lane;
+        const int xx = e % RW, r = e / RW, yy = r % (TY + 2), zz = r / (TY + 2);
+        const bool ok = xx < nx + 2 && yy < ny + 2 && zz < nz + 2;
+        at[u] = ok ? zz * PY + yy * PX + xx : -1;
+        tmp[u] = ok ? org[xx + (long long)g.px * yy + g.pz * zz] : (T)0;
+      }
+#pragma unroll
+      for (int u = 0; u < BATCH; ++u)
+        if (at[u] >= 0) t[at[u]] = tmp[u];
+    }
+    __syncthreads();
+    const int cls = mgx_classify(boxes, nb, x0, x0 + nx - 1, y0, y0 + ny - 1, z0 + g.z0, z0 + nz - 1 + g.z0);
+    const int j = lane & 7, k = lane >> 3;
+    const bool coded = cls != 0 && nb <= 32;             // codes and weight tables instead of scans of the box table
+    if (coded) {
+      unsigned cmask = 0u, rmask = 0u;
+      for (int b = 0; b < nb; ++b) {
+        cmask |= sbx[b].constant ? (1u << b) : 0u;
+        rmask |= sbx[b].rho_is_one ? 0u : (1u << b);
+      }
+      const unsigned tb0 = rmask & (0u - rmask), tb1 = (rmask ^ tb0) & (0u - (rmask ^ tb0));
+      if (lane < TX + 2 + TY + 2 + TZ + 2) {
+        const int dim = lane < TX + 2 ? 0 : lane < TX + 2 + TY + 2 ? 1 : 2;
+        const int l = dim == 0 ? lane : dim == 1 ? lane - (TX + 2) : lane - (TX + 2 + TY + 2);
+        const int pos = (dim == 0 ? x0 : dim == 1 ? y0 : z0 + g.z0) - 1 + l;
+        unsigned set = 0u;
+        for (int b = 0; b < nb; ++b) set |= (sbx[b].lo[dim] <= pos && pos <= sbx[b].hi[dim]) ? (1u << b) : 0u;
+        (dim == 0 ? bl.xs : dim == 1 ? bl.ys : bl.zs)[l] = set;
+      }
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int m = lane;
+        const unsigned tb = h ? tb1 : tb0;
+        const T rb = tb ? (T)sbx[__ffs((int)tb) - 1].rho : (T)1;
+        T r[6];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) r[i] = (((m >> i) & 1) ? rb : (T)1) * p.a[i >> 1];
+        T sm = r[0];
+        sm = sm + r[1]; sm = sm + r[2]; sm = sm + r[3]; sm = sm + r[4]; sm = sm + r[5];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) bl.wtab[h][m][i] = r[i] / sm;
+      }
+      __syncthreads();
+      if (j < ny && k < nz) {
+        const uint4 ys4 = make_uint4(bl.ys[j], bl.ys[j + 1], bl.ys[j + 2], 0u);
+        const unsigned zl = bl.zs[k], zc = bl.zs[k + 1], zh = bl.zs[k + 2];
+        for (int i = 0; i < nx; ++i)
+          bl.code[(k * TY + j) * TX + i] =
+              (unsigned short)mgx_cell_code(bl.xs[i + 1], bl.xs[i], bl.xs[i + 2], ys4, zl, zc, zh, cmask, rmask, tb0, tb1);
+      }
+      __syncthreads();
+    }
+    const bool mine = j < ny && k < nz;
+    T *c0 = t + (k + 1) * PY + (j + 1) * PX + 1;          // cell i = 0 of this lane's row
+    for (int m = 0; m < nx + ny + nz - 2; ++m) {
+      const int i = m - j - k;
+      if (mine && i >= 0 && i < nx) {
+        T *c = c0 + i;
+        const T vc = c[0];
+        T vv;
+        if (coded) {
+          const unsigned code = bl.code[(k * TY + j) * TX + i];
+          const T *w = &bl.wtab[0][0][0] + (code & 127u) * 6u;
+          T avg = c[-1] * w[0] + c[1] * w[1];
+          avg = avg + c[-PX] * w[2];
+          avg = avg + c[PX] * w[3];
+          avg = avg + c[-PY] * w[4];
+          avg = avg + c[PY] * w[5];
+          if (code & MGX_CODE_GENERAL)
+            avg = mgx_avg_general<T>(c[-1], c[1], c[-PX], c[PX], c[-PY], c[PY], boxes, nb, x0 + i, y0 + j, z0 + k + g.z0, p.a);
+          avg = (code & MGX_CODE_CONST) ? vc : avg;
+          vv = p.s1 * vc + p.s2 * avg;
+        } else {
+          vv = mgx_cell_new<T>(vc, c[-1], c[1], c[-PX], c[PX], c[-PY], c[PY], cls, boxes, nb, x0 + i, y0 + j,
+                               z0 + k + g.z0, p);
+        }
+        const T dv = vv - vc;
+        const T d2 = dv * dv;
+        err = d2 > err ? d2 : err;
+        c[0] = vv;
+      }
+      __syncthreads();
+    }
+    for (int r = lane >> 3; r < ny * nz; r += 8) {
+      const int yy = r % ny, zz = r / ny;
+      T *row = V + g.idx(x0, y0 + yy, z0 + zz);
+      for (int xx = lane & 7; xx < nx; xx += 8) row[xx] = t[(zz + 1) * PY + (yy + 1) * PX + xx + 1];
+    }
+  }
+  if (reduce & 1) mgx_block_commit<1>((double)err, 0ull, 0ull, 0u, 1, res);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -700,6 +863,66 @@ __global__ __launch_bounds__(256) void k_prolong(const T *__restrict__ src, cons
             for (int px = xr.x; px <= xr.y; ++px) row[px] = v;
           }
         }
+    }
+  }
+}
+
+// The same for a parent exactly twice as wide as the child (n1 = 2 nc1: g2g gives child 1 the parents 1, 2, 3, child
+// c the parents 2c, 2c+1 and child nc1 the parent 2 nc1).  A store of the two parents of one child would start at an
+// even x, 8 bytes off the 16-byte grid of a row that starts at x = 1, so every wave would write two partial lines;
+// here a lane writes the aligned pair (2c-1, 2c) instead, i.e. the value of child c-1 (of child 1 itself for c = 1) and
+// its own, and evaluates both stencils from a patch one column wider (the left one is the very expression the
+// neighbouring lane evaluates: same bits).
+template <typename T, bool HALF, int ZCH>
+__global__ __launch_bounds__(256) void k_prolong_xhalved(const T *__restrict__ src, const MgxGeom gs, T *__restrict__ dst,
+                                                         const MgxGeom gd, const int2 *__restrict__ ry,
+                                                         const int2 *__restrict__ rz, const int czg0, const int czg1) {
+  const int cx = blockIdx.x * 64 + (threadIdx.x & 63) + 1;
+  const int cy = blockIdx.y * 4 + (threadIdx.x >> 6) + 1;
+  const int cbeg = czg0 + blockIdx.z * ZCH, cend = min(cbeg + ZCH - 1, czg1);
+  if (cx > gs.n1 || cy > gs.n2) return;
+  const int2 yr = ry[cy];
+  if (yr.x > yr.y) return;
+  typedef T pair_t __attribute__((ext_vector_type(2)));     // 16-byte aligned in memory: x = 2 cx - 1 is odd
+  const long long sy = gs.px;
+  const int dl = cx == 1 ? -1 : -2;                        // child 1 has no left neighbour to serve: any valid column
+  T W[3][12];                                              // q[(dy+1)*4 + c], c = 0: column cx-2 ... 3: column cx+1
+  auto fetch = [&](T (&q)[12], const int czl) {
+    const T *c = src + gs.idx(cx, cy, czl);
+#pragma unroll
+    for (int dy = -1; dy <= 1; ++dy) {
+      q[(dy + 1) * 4 + 0] = c[dl + sy * dy];
+#pragma unroll
+      for (int dx = -1; dx <= 1; ++dx) q[(dy + 1) * 4 + dx + 2] = c[dx + sy * dy];
+    }
+  };
+  auto eval = [&](const T (&zm)[12], const T (&z0)[12], const T (&zp)[12], const int o) -> T {
+    T a[9], b[9], c[9];
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+      for (int k = 0; k < 3; ++k) { a[r * 3 + k] = zm[r * 4 + k + o]; b[r * 3 + k] = z0[r * 4 + k + o]; c[r * 3 + k] = zp[r * 4 + k + o]; }
+    return mgx_prolong_from_planes<T, HALF>(a, b, c);
+  };
+  fetch(W[0], cbeg - 1 - gs.z0);
+  fetch(W[1], cbeg - gs.z0);
+  for (int cb = cbeg; cb <= cend; cb += 3) {
+#pragma unroll
+    for (int u = 0; u < 3; ++u) {
+      const int czg = cb + u;
+      if (czg > cend) break;
+      fetch(W[(u + 2) % 3], czg + 1 - gs.z0);
+      const T v = eval(W[u % 3], W[(u + 1) % 3], W[(u + 2) % 3], 1);
+      const T vl = eval(W[u % 3], W[(u + 1) % 3], W[(u + 2) % 3], 0);
+      int2 zr = rz[czg];
+      zr.x = max(zr.x, gd.z0 + 1) - gd.z0;
+      zr.y = min(zr.y, gd.z0 + gd.n3) - gd.z0;
+      pair_t vv;
+      vv.x = cx == 1 ? v : vl;
+      vv.y = v;
+      for (int pz = zr.x; pz <= zr.y; ++pz)
+        for (int py = yr.x; py <= yr.y; ++py)
+          __builtin_nontemporal_store(vv, reinterpret_cast<pair_t *>(dst + gd.idx(2 * cx - 1, py, pz)));
     }
   }
 }

@@ -47,7 +47,7 @@ def run_case(ctx, n, dtype, boxes, bc, sor, kernel, sweeps=3, seed=0, scale=1.0,
         assert lv.count_nonconst() == orc.count_nonconst(L)
         for k in range(sweeps):
             red = (3, 1, 2, 0)[k % 4]
-            e2 = orc.sweep(L, V, orc.ORDER_RB)
+            e2 = orc.sweep(L, V, orc.ORDER_LEX if kernel == 4 else orc.ORDER_RB)   # kernel 4: the reference's own order
             s, big = orc.abs_sum_exact(L, V)
             lv.sweep(1, red)
             de2, ds, dbig = lv.result() if red else (None, None, None)
@@ -62,7 +62,7 @@ def run_case(ctx, n, dtype, boxes, bc, sor, kernel, sweeps=3, seed=0, scale=1.0,
         ctx.set_kernel(0)
 
 
-@pytest.mark.parametrize("kernel", [1, 2])
+@pytest.mark.parametrize("kernel", [1, 2, 4])
 @pytest.mark.parametrize("n", [(1, 1, 1), (2, 1, 3), (3, 3, 3), (5, 2, 7), (1, 9, 4), (17, 1, 1)])
 def test_tiny_levels(ctx, n, kernel):
     rng = np.random.default_rng(sum(n))
@@ -70,7 +70,7 @@ def test_tiny_levels(ctx, n, kernel):
         run_case(ctx, n, dtype, random_boxes(rng, n, 2), (1, 3, 2, 1, 3, 2), 1.5, kernel, seed=sum(n))
 
 
-@pytest.mark.parametrize("kernel", [1, 2])
+@pytest.mark.parametrize("kernel", [1, 2, 4])
 @pytest.mark.parametrize("dtype", [np.float64, np.float32])
 @pytest.mark.parametrize("seed", [1, 2, 3])
 def test_random_boxes_across_tiles(ctx, seed, dtype, kernel):
@@ -80,7 +80,7 @@ def test_random_boxes_across_tiles(ctx, seed, dtype, kernel):
     run_case(ctx, n, dtype, random_boxes(rng, n, 3 * seed), (1, 1, 2, 3, 3, 2), 1.6, kernel, seed=seed)
 
 
-@pytest.mark.parametrize("kernel", [1, 2])
+@pytest.mark.parametrize("kernel", [1, 2, 4])
 def test_nested_and_adjacent_rho_boxes(ctx, kernel):
     """three boxes with rho != 1 touching each other and a constant box inside one of them"""
     n = (150, 44, 36)
@@ -100,6 +100,23 @@ def test_more_boxes_than_bit_sets(ctx):
     run_case(ctx, n, np.float64, boxes, (1, 1, 2, 2, 3, 3), 1.5, 0, seed=40)
     with pytest.raises(lib.MgxError):
         run_case(ctx, n, np.float64, boxes, (1, 1, 2, 2, 3, 3), 1.5, 2, seed=40)
+    run_case(ctx, n, np.float64, boxes, (1, 1, 2, 2, 3, 3), 1.5, 4, seed=40)      # the reference's order scans the table
+
+
+@pytest.mark.parametrize("tiled", ["1", "0"])
+def test_reference_order_by_tiles_and_by_cells(ctx, tiled, monkeypatch):
+    """the two forms of the reference-order sweep (tile hyperplanes, cell hyperplanes) against the oracle's
+    lexicographic sweep on a level with partial tiles in every direction"""
+    from multigrid_amd import lib
+    monkeypatch.setenv("MGX_LEX_TILED", tiled)
+    c = lib.Context(0)                      # the switch is read when a context is created
+    try:
+        rng = np.random.default_rng(11)
+        n = (75, 19, 21)
+        run_case(c, n, np.float64, random_boxes(rng, n, 6), (1, 1, 3, 2, 2, 3), 1.8, 4, sweeps=4, seed=11)
+        run_case(c, n, np.float32, [], (1, 1, 1, 1, 1, 1), 1.9, 4, sweeps=4, seed=12)
+    finally:
+        c.close()
 
 
 @pytest.mark.parametrize("kernel", [1, 2])
