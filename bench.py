@@ -398,6 +398,18 @@ def main():
                                         "frac": BYTES_PER_LUP * local_cells / (pk * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                         "glups": 2 * local_cells / (pk * 1e-3) / 1e9}
 
+    if world == 1:
+        # the same sweep in the reference's own order (MGX_KERNEL_LEX: results of the reference on one thread, bit for
+        # bit), for the record: it is the slow, order-faithful mode, not the metric
+        ctx.set_kernel(lib.KERNEL_LEX)
+        try:
+            step()
+            lk, _ = timed(step, 5)
+            out["reference_order"] = {"kernel_ms": lk, "glups": local_cells / (lk * 1e-3) / 1e9,
+                                      "note": "gs in the reference's sweep order by tile hyperplanes, both reductions"}
+        finally:
+            ctx.set_kernel(args.kernel)
+
     if world == 1 and not args.no_vcycle:
         # complete `method v-cycle` solve of the same input (fresh state), timed to its own tolerance
         for g in top.levels():

@@ -49,7 +49,10 @@ static int mgx_fused_make_plan(MgxFusedPlan &pl, const MgxGeom &g, const std::ve
   pl.ns = ns;
   const int reach = 2 * ns;      // a tile reads cells up to this far outside its footprint
   // 128 x 20 tiles on 8 row waves measured fastest on large levels; small levels take the small tile
-  if (g.n1 >= 96 && g.n2 >= 40) { pl.ty = 20; pl.nw = 8; } else { pl.ty = 8; pl.nw = 4; }
+  // (measured per sweep, fp64: 128^3 23 us on 128 x 12 tiles against 29 on 128 x 20; 64^3 16 against 22 on 128 x 8 tiles
+  // of 4 row waves; 256^3 and larger are faster on 128 x 20)
+  const bool large = g.n1 >= 96 && g.n2 >= 40 && (long long)g.n1 * g.n2 * g.n3 > 4000000LL;
+  if (large) { pl.ty = 20; pl.nw = 8; } else { pl.ty = 12; pl.nw = 8; }
   if (mgx_fused_ty > 0) {
     const int want = mgx_fused_ty * 100 + mgx_fused_nw;
     if (want == 804 || want == 1208 || want == 2008 || want == 2006 || want == 2606 || want == 3206) {
@@ -68,7 +71,15 @@ static int mgx_fused_make_plan(MgxFusedPlan &pl, const MgxGeom &g, const std::ve
   while (ZC > 32 * ns && per_chunk * ((g.n3 + ZC - 1) / ZC) < 768) ZC = (ZC + 1) / 2;
   // small levels live in the caches and their sweeps are bound by the length of the march: shorter chunks until
   // the blocks fill the compute units about twice (measured: 256^3 best at 16 planes, 128^3 and below at 4)
-  while (ZC > (ns == 1 ? 4 : 16) && per_chunk * ((g.n3 + ZC - 1) / ZC) < 400) ZC = (ZC + 1) / 2;
+  // (levels of a few tiles per chunk: 2 planes; 64^3 and 32^3 16 us against 20 with 4)
+  const int zmin = ns == 1 ? (per_chunk <= 8 ? 2 : 4) : 16;
+  while (ZC > zmin && per_chunk * ((g.n3 + ZC - 1) / ZC) < 400) ZC = (ZC + 1) / 2;
+  // chunks of 20 planes instead of 16 where that still leaves 300 pieces and less work in all (a piece costs its
+  // planes, the four it reads ahead and its start; 256^3: 74 us per sweep against 80)
+  if (ns == 1 && ZC == 16 && g.n3 > 20) {
+    const long long p16 = per_chunk * ((g.n3 + 15) / 16), p20 = per_chunk * ((g.n3 + 19) / 20);
+    if (p20 >= 300 && p20 * 27 < p16 * 23) ZC = 20;
+  }
   if (mgx_fused_zc > 0) ZC = std::min(mgx_fused_zc, g.n3);
   pl.ZC = ZC;
   pl.nzc = (g.n3 + ZC - 1) / ZC;
