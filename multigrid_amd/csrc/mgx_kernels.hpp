@@ -383,7 +383,9 @@ __global__ __launch_bounds__(256) void k_lex_plane(T *__restrict__ V, const MgxG
 // it by the hyperplanes i + j + k = m of the tile (lane = (j, k), i = m - j - k: at most one cell per lane and step,
 // every operand in LDS as the order demands) and writes the tile back.  Same bits as k_lex_plane, with rows of
 // MGX_LEX_TX cells moved at a time and (TX + TY + TZ - 2) steps per launch instead of one.
-#define MGX_LEX_TX 32
+#ifndef MGX_LEX_TX
+#define MGX_LEX_TX 8      /* measured per sweep, fp64 with boxes: 64^3 0.31 ms (0.47 with 32), 256^3 1.36 (1.99), 512^3 4.1 (4.6) */
+#endif
 #define MGX_LEX_TY 8
 #define MGX_LEX_TZ 8
 template <typename T>
