@@ -275,6 +275,11 @@ def main():
     ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     RED = lib.RED_ERR | lib.RED_SUM
 
+    def progress(msg):
+        """a line on stderr between the phases (stdout carries the one JSON line only)"""
+        if rank == 0:
+            print(f"[bench] {msg}", file=sys.stderr, flush=True)
+
     def timed(fn, reps):
         """device time per call of fn on the library's stream (HIP events) and host wall time per call"""
         torch.cuda.synchronize()
@@ -326,6 +331,7 @@ def main():
                     f"and the halo exchange per step")
         scaling = "strong"
 
+    progress(f"levels set up; {args.warmup} warm-up and {args.steps} timed steps")
     for _ in range(args.warmup):
         step()
     fetch()
@@ -360,6 +366,7 @@ def main():
         "check": {"err_sq_max": e2, "abs_sum": s},
     }
     if world > 1 and not args.no_verify:
+        progress("steps timed; rank 0 repeats them on the undivided level")
         # rank 0 repeats the same sweeps on the undivided level (it fits one GPU) and compares the reductions of the
         # last sweep bit for bit: red-black results and the exact sum do not depend on the decomposition
         if rank == 0:
@@ -411,6 +418,7 @@ def main():
             ctx.set_kernel(args.kernel)
 
     if world == 1 and not args.no_vcycle:
+        progress("steps timed; v-cycle solve of the same input")
         # complete `method v-cycle` solve of the same input (fresh state), timed to its own tolerance
         for g in top.levels():
             g.itt = 0
@@ -449,6 +457,7 @@ def main():
                                                            "frac": BYTES_PER_LUP * local_cells / (pk * 1e-3) / 1e9 / HBM_PEAK_GBS}
     exe = os.path.join(ROOT, "multigrid_amd", "fortran", "mg_gpu_f64")
     if world == 1 and not args.no_vcycle and not args.no_fortran_host and os.path.exists(exe):
+        progress("v-cycle solve done; the same solve through the Fortran host")
         # the same solve driven by the Fortran host (the reference's cycle control over the C ABI, ISO_C_BINDING), as
         # a child process with a context of its own
         with tempfile.TemporaryDirectory() as td:
@@ -464,6 +473,7 @@ def main():
             except Exception as e:
                 out["vcycle_fortran_host"] = {"seconds": None, "error": str(e)}
     if world > 1 and not args.no_dist_vcycle:
+        progress("v-cycle solve of config 3 with every level decomposed over the ranks")
         # the headline solve (config 3, tol 1e-8) with every level of the hierarchy as z slabs aligned between levels over
         # the N GPUs: transfers are local, each is followed by one halo refresh, reductions are all-reduced (exact
         # sum: identical on every rank), thin coarse levels are held whole by every rank
@@ -489,6 +499,7 @@ def main():
         except Exception as e:
             out["vcycle"] = {"seconds": None, "status": f"stopped: {e}", "tol": float(args.vcycle_tol)}
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        progress("CPU baseline: the reference's smoother on the host cores")
         out["cpu_baseline"] = cpu_baseline()
     if rank == 0:
         print(json.dumps(out), flush=True)
