@@ -18,6 +18,10 @@ module mgx_c
        import :: c_ptr
        type(c_ptr) :: msg
      end function mgx_last_error
+     function mgx_version() bind(C, name="mgx_version") result(msg)
+       import :: c_ptr
+       type(c_ptr) :: msg
+     end function mgx_version
      function mgx_ctx_create(device, stream, ctx) bind(C, name="mgx_ctx_create") result(rc)
        import :: c_int, c_ptr
        integer(c_int), value :: device
