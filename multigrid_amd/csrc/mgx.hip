@@ -96,6 +96,7 @@ struct mgx_level {
   bool shell_synced = false;   // buf[1-cur] holds the same ghost shell as buf[cur]
   bool defined = false;        // field content is meaningful
   bool inner_pending = false;  // mgx_level_sweep_part: the edge part ran, the inner part is due
+  int part_reduce = 0;         // the reductions the edge part was asked for (the inner part must ask for the same)
   bool zero_pending = false;   // brought back but not yet zero-filled: the next reader fills, a full overwrite skips it
   // parameters
   double sor = 1.8;
@@ -789,8 +790,12 @@ static int do_sweep_part(mgx_level *lv, int part, int reduce) {
     HIP_TRY(hipGetLastError());
     lv->cur = 1 - lv->cur;
     lv->inner_pending = true;
+    lv->part_reduce = reduce;
   } else {
     if (!lv->inner_pending) return fail(MGX_ESTATE, "mgx_level_sweep_part: the inner part follows the edge part");
+    // the blocks of both launches count towards one fold of the reductions (mgx_block_commit)
+    if (reduce != lv->part_reduce)
+      return fail(MGX_EINVAL, "mgx_level_sweep_part: reduce = %d in the inner part, %d in the edge part", reduce, lv->part_reduce);
     if (mgx_fused_launch(lv->plan, 2, (const T *)lv->buf[1 - lv->cur], (T *)lv->buf[lv->cur], g, make_params<T>(lv),
                             lv->d_boxes, lv->nbox, reduce, lv->d_res, C(lv)->stream) != 0)
       return fail(MGX_EHIP, "mgx_level_sweep_part: fused kernel launch configuration failed");

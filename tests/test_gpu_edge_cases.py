@@ -147,6 +147,15 @@ def test_error_codes(ctx):
             lv.half_sweep(2, 1, 8, 0)
         with pytest.raises(lib.MgxError):
             lv.sweep_part(lib.PART_INNER, 0)    # inner part without its edge part
+        lv.set_boxes([], [], [], [])
+        lv.bring_back()
+        lv.setup(True)
+        lv.sweep_part(lib.PART_EDGE, 3)
+        with pytest.raises(lib.MgxError) as e:
+            lv.sweep_part(lib.PART_INNER, 1)    # the two parts of a sweep share one fold of the reductions
+        assert e.value.code == -1
+        lv.sweep_part(lib.PART_INNER, 3)
+        lv.result()
         with pytest.raises(lib.MgxError):
             lv.plane_ptr(11, 1)
     finally:
