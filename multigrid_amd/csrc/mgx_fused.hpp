@@ -185,7 +185,8 @@ __device__ __forceinline__ void mgx_stream_store(const mgx_f2v v, mgx_f2v *ptr) 
 __device__ __forceinline__ double mgx_max_abs(double m, double d) { return __builtin_fmax(m, __builtin_fabs(d)); }
 __device__ __forceinline__ float mgx_max_abs(float m, float d) { return __builtin_fmaxf(m, __builtin_fabsf(d)); }
 
-// branch-free form of mgx_exact_add (same integer result)
+// branch-free form of mgx_exact_add (same integer result: a value with bits below the grid of the sum is rounded
+// to nearest, ties to even, exactly as there and as in the two-double partial sums)
 __device__ inline void mgx_exact_add_nb(u64 &lo, u64 &hi, double a, unsigned &ovf) {
   const u64 bits = (u64)__double_as_longlong(a) & 0x7FFFFFFFFFFFFFFFull;
   const int e = (int)(bits >> 52);
@@ -193,8 +194,12 @@ __device__ inline void mgx_exact_add_nb(u64 &lo, u64 &hi, double a, unsigned &ov
   ovf |= (e >= 1023 + 20) ? 1u : 0u;
   m |= e ? (1ull << 52) : 0ull;
   const int sh = (e ? e : 1) - 1075 + MGX_SUM_Q;
-  const int shl = min(max(sh, 0), 63), shr = min(max(-sh, 0), 63);
-  const u64 alo = sh >= 0 ? (m << shl) : (m >> shr);
+  const int shl = min(max(sh, 0), 63), shr = min(max(-sh, 0), 63);    // m < 2^53: a shift of 63 stands for any longer one
+  const u64 q = m >> shr;
+  const u64 rem = m & ((1ull << shr) - 1ull);                         // shr = 0: nothing is cut off
+  const u64 half = shr ? (1ull << (shr - 1)) : ~0ull;
+  const u64 up = (rem > half || (rem == half && (q & 1ull))) ? 1ull : 0ull;
+  const u64 alo = sh >= 0 ? (m << shl) : q + up;
   const u64 ahi = sh >= 0 ? ((m >> 1) >> (63 - shl)) : 0ull;
   lo += alo;
   hi += ahi + (lo < alo ? 1ull : 0ull);

@@ -31,11 +31,13 @@ def random_boxes(rng, n, nbox, rhos=(1.0, 3.0, 0.25, 7.5)):
     return boxes
 
 
-def run_case(ctx, n, dtype, boxes, bc, sor, kernel, sweeps=3, seed=0, scale=1.0, a=(0.3, 0.3, 0.4)):
+def run_case(ctx, n, dtype, boxes, bc, sor, kernel, sweeps=3, seed=0, scale=1.0, a=(0.3, 0.3, 0.4), spikes=0):
     from multigrid_amd import lib
     L = orc.Level(n=tuple(n), bc=tuple(bc), sor=sor, a=a, boxes=boxes)
     rng = np.random.default_rng(seed)
     V = (rng.standard_normal(L.shape()) * scale).astype(dtype)
+    for _ in range(spikes):                 # a few cells far above the rest of the field
+        V[tuple(int(rng.integers(1, d + 1)) for d in reversed(n))] = 5000.0 * float(rng.uniform(1, 8))
     orc.setup(L, V, False)
     ctx.set_kernel(kernel)
     lv = ctx.level(1, n, dtype)
@@ -124,6 +126,14 @@ def test_sum_beyond_the_fast_range(ctx, kernel):
     """|V| up to ~1e5: the two-double partial sums hand over to the integer path, same exact sum"""
     n = (140, 24, 10)
     run_case(ctx, n, np.float64, [], (1, 1, 1, 1, 1, 1), 1.2, kernel, seed=3, scale=3.0e4)
+
+
+@pytest.mark.parametrize("kernel", [1, 2, 3])
+def test_sum_of_tiny_values_beside_large_ones(ctx, kernel):
+    """a field of values around 1e-9 (bits far below the 2^-72 grid of the sum) with a few cells beyond the fast
+    range: the lanes that share a wave with a large value take the integer path and must round, not truncate"""
+    n = (140, 24, 10)
+    run_case(ctx, n, np.float64, [], (1, 1, 1, 1, 1, 1), 1.0, kernel, sweeps=5, seed=5, scale=1.0e-9, spikes=6)
 
 
 def test_error_codes(ctx):

@@ -85,3 +85,16 @@ def test_pair_pass_tiles_and_boxes(ctx, case, prec):
     V = rng.standard_normal((n[2] + 2, n[1] + 2, n[0] + 2)).astype(prec)
     orc.setup(L, V, False)
     run_case(ctx, L, V, [2, 5])
+
+
+def test_pair_pass_sum_of_tiny_values_beside_large_ones(ctx):
+    """values around 1e-9 (bits far below the 2^-72 grid of the sum) with a few cells beyond the fast range of the
+    partial sums: lanes that share a wave with a large value take the integer path and must round like the rest"""
+    n = (140, 44, 12)
+    L = random_level(n, (1, 1, 1, 1, 1, 1), [], sor=1.0)
+    rng = np.random.default_rng(7)
+    V = (rng.standard_normal((n[2] + 2, n[1] + 2, n[0] + 2)) * 1.0e-9).astype(np.float64)
+    for _ in range(6):
+        V[tuple(int(rng.integers(1, d + 1)) for d in reversed(n))] = 5000.0 * float(rng.uniform(1, 8))
+    orc.setup(L, V, False)
+    run_case(ctx, L, V, [2, 4])
