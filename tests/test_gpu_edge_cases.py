@@ -170,3 +170,38 @@ def test_error_codes(ctx):
             lv.plane_ptr(11, 1)
     finally:
         lv.close()
+
+
+@pytest.mark.parametrize("spikes", [0, 5])
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("kernel", [1, 2, 3])
+def test_sum_of_values_halfway_between_grid_points(ctx, kernel, dtype, spikes):
+    """every |V| is an odd multiple of 2^-73, exactly halfway between two points of the 2^-72 grid the sum rounds to:
+    all forms of the add (two-double partial sums, integer path beside values beyond the fast range, the plain
+    grid_sum kernel) must break the tie to even like the oracle's integer arithmetic.  sor = 0 keeps the field as it
+    is (V = 1*V + 0*avg), so the sweeps' own reductions see exactly these values."""
+    from multigrid_amd import lib
+    n = (140, 30, 9)
+    L = orc.Level(n=n, bc=(1,) * 6, sor=0.0, a=(0.3, 0.3, 0.4), boxes=[])
+    rng = np.random.default_rng(17 + spikes)
+    m = rng.integers(0, 1 << 20, size=L.shape())
+    V = (np.ldexp((2 * m + 1).astype(np.float64), -73) * rng.choice([-1.0, 1.0], size=L.shape())).astype(dtype)
+    assert np.array_equal(V.astype(np.float64) * 2.0 ** 73 % 2, np.ones(L.shape()))      # nothing was rounded away
+    for _ in range(spikes):
+        V[tuple(int(rng.integers(1, d + 1)) for d in reversed(n))] = 4096.0
+    s, big = orc.abs_sum_exact(L, V)
+    ctx.set_kernel(kernel)
+    lv = ctx.level(1, n, dtype)
+    try:
+        lv.set_params(0.0, (0.3, 0.3, 0.4), (1,) * 6)
+        lv.set_boxes([], [], [], [])
+        lv.upload(V)
+        assert lv.abs_sum_limbs() == big
+        for nsw in (1, 2):
+            lv.sweep(nsw, lib.RED_ERR | lib.RED_SUM)
+            de2, ds, dbig = lv.result()
+            assert bits_equal(lv.download(), V)
+            assert de2 == 0.0 and dbig == big and ds == s
+    finally:
+        lv.close()
+        ctx.set_kernel(0)
