@@ -1,0 +1,160 @@
+"""Randomised parity run on the GPU box: random level shapes, boundary conditions, box tables, relaxation factors,
+magnitudes, kernels and sweep counts; the library's fields, max dV^2 and exact sums against the CPU oracle, bit for
+bit.  Usage: python scripts/fuzz_parity.py [cases] [seed] [transfers]
+(with `transfers`: restriction and prolongation between random pairs of levels instead of sweeps).  Prints one line per 10 cases; stops at the first mismatch
+with the parameters that reproduce it."""
+import sys
+import time
+
+import numpy as np
+
+from multigrid_amd import lib
+from oracle import oracle as orc
+
+
+def random_boxes(rng, n, nbox):
+    boxes = []
+    for _ in range(nbox):
+        lo = [int(rng.integers(1, d + 1)) for d in n]
+        hi = [int(min(d, l + rng.integers(0, max(1, d // 2) + 1))) for d, l in zip(n, lo)]
+        constant = bool(rng.integers(0, 3) == 0)
+        rho = 1.0 if constant else float(rng.choice([1.0, 3.0, 0.25, 7.5]))
+        boxes.append(orc.Box((lo[0], hi[0], lo[1], hi[1], lo[2], hi[2]), float(rng.uniform(-1, 1)), rho, constant))
+    return boxes
+
+
+def bits_equal(a, b):
+    u = np.uint64 if a.dtype == np.float64 else np.uint32
+    return a.shape == b.shape and np.array_equal(a.view(u), b.view(u))
+
+
+def one_case(ctx, rng, idx):
+    dims = [1, 2, 3, 5, 8, 17, 31, 64, 65, 127, 128, 129, 140, 200, 257, 300]
+    n = (int(rng.choice(dims)), int(rng.choice(dims[:12])), int(rng.choice(dims[:11])))
+    if rng.integers(0, 4) == 0:
+        n = tuple(int(rng.integers(1, 90)) for _ in range(3))
+    dtype = np.float64 if rng.integers(0, 2) else np.float32
+    kernel = int(rng.choice([0, 1, 2, 3, 4]))
+    bc = tuple(int(rng.integers(1, 4)) for _ in range(6))
+    for ax in range(3):                                   # a periodic face comes with its partner
+        if lib.BC_PERIODIC in (bc[2 * ax], bc[2 * ax + 1]):
+            bc = bc[:2 * ax] + (lib.BC_PERIODIC,) * 2 + bc[2 * ax + 2:]
+    sor = float(rng.choice([1.0, 1.2, 1.5, 1.7, 0.8]))
+    a = rng.uniform(0.1, 1.0, 3)
+    a = tuple(float(v) for v in a / a.sum())
+    nbox = int(rng.choice([0, 0, 1, 2, 4, 7]))
+    boxes = random_boxes(rng, n, nbox)
+    scale = float(rng.choice([1.0, 1.0, 1.0e-9, 1.0e-3, 50.0, 3.0e3]))
+    desc = dict(idx=idx, n=n, dtype=np.dtype(dtype).name, kernel=kernel, bc=bc, sor=sor, a=a, nbox=nbox, scale=scale)
+    L = orc.Level(n=n, bc=bc, sor=sor, a=a, boxes=boxes)
+    V = (rng.standard_normal(L.shape()) * scale).astype(dtype)
+    if rng.integers(0, 4) == 0:
+        for _ in range(3):
+            V[tuple(int(rng.integers(1, d + 1)) for d in reversed(n))] = 3000.0 * float(rng.uniform(1, 5))
+    orc.setup(L, V, False)
+    ctx.set_kernel(kernel)
+    lv = ctx.level(1, n, dtype)
+    try:
+        lv.set_params(sor, a, bc)
+        lv.set_boxes([b.place for b in boxes], [b.val for b in boxes], [b.rho for b in boxes], [int(b.constant) for b in boxes])
+        lv.upload(V)
+        lv.setup(False)
+        assert lv.count_nonconst() == orc.count_nonconst(L), ("count", desc)
+        for k in range(3):
+            nsw = int(rng.integers(1, 5))
+            red = int(rng.choice([0, 1, 2, 3, 3]))
+            for _ in range(nsw):
+                e2 = orc.sweep(L, V, orc.ORDER_LEX if kernel == 4 else orc.ORDER_RB)
+            s, big = orc.abs_sum_exact(L, V)
+            try:
+                lv.sweep(nsw, red)
+            except lib.MgxError as e:
+                if e.code == -5 and kernel in (2, 3):     # a forced kernel may refuse a shape
+                    return
+                raise
+            W = lv.download()
+            assert bits_equal(W, V), ("field", k, nsw, red, desc)
+            if red:
+                de2, ds, dbig = lv.result()
+                if red & 1:
+                    assert de2 == e2, ("err", k, nsw, red, de2, e2, desc)
+                if red & 2:
+                    assert dbig == big and (ds == s or (ds != ds and s != s)), ("sum", k, nsw, red, dbig, big, desc)
+            assert lv.abs_sum_limbs() == big, ("abs_sum", k, desc)
+    finally:
+        lv.close()
+        ctx.set_kernel(0)
+
+
+def dev_level(ctx, L, dtype, layer):
+    lv = ctx.level(layer, L.n, dtype)
+    lv.set_params(L.sor, L.a, L.bc)
+    lv.set_boxes([b.place for b in L.boxes], [b.val for b in L.boxes], [b.rho for b in L.boxes],
+                 [int(b.constant) for b in L.boxes])
+    return lv
+
+
+def one_transfer(ctx, rng, idx):
+    """grid_restriction and grid_prolongation (both end in grid_setup of the level they write) between a parent and a
+    child whose extents are halved, halved and rounded either way, or unrelated"""
+    dims = [2, 3, 4, 7, 8, 15, 16, 30, 31, 32, 33, 64, 66, 100, 128, 130, 200, 256, 258]
+    n = (int(rng.choice(dims)), int(rng.choice(dims[:13])), int(rng.choice(dims[:12])))
+
+    def child(d):
+        k = int(rng.integers(0, 5))
+        c = [d // 2, (d + 1) // 2, (d + d % 2) // 2 - 1, int(rng.integers(1, d + 1)), d // 2][k]
+        return max(1, c)
+    nc = tuple(child(d) for d in n)
+    if rng.integers(0, 3) == 0:
+        nc = tuple(d // 2 if d % 2 == 0 else c for d, c in zip(n, nc))     # the plain halving wherever it exists
+    dtype = np.float64 if rng.integers(0, 2) else np.float32
+    method = int(rng.integers(1, 3))
+    bc = tuple(int(rng.integers(1, 4)) for _ in range(6))
+    for ax in range(3):
+        if lib.BC_PERIODIC in (bc[2 * ax], bc[2 * ax + 1]):
+            bc = bc[:2 * ax] + (lib.BC_PERIODIC,) * 2 + bc[2 * ax + 2:]
+    desc = dict(idx=idx, n=n, nc=nc, dtype=np.dtype(dtype).name, method=method, bc=bc)
+    P = orc.Level(n=n, bc=bc, boxes=random_boxes(rng, n, int(rng.choice([0, 1, 3]))), res_method=method, pro_method=method)
+    Cl = orc.Level(n=nc, bc=bc, boxes=random_boxes(rng, nc, int(rng.choice([0, 1, 3]))), res_method=method, pro_method=method)
+    dp, dc = dev_level(ctx, P, dtype, 1), dev_level(ctx, Cl, dtype, 2)
+    try:
+        Vp = rng.standard_normal(P.shape()).astype(dtype)
+        Vc = np.zeros(Cl.shape(), dtype=dtype)
+        dp.upload(Vp)
+        dc.bring_back()
+        orc.restrict(P, Vp, Cl, Vc)
+        lib.restrict(dp, dc, method)
+        assert bits_equal(dc.download(), Vc), ("restrict", desc)
+        Vc = rng.standard_normal(Cl.shape()).astype(dtype)
+        dc.upload(Vc)
+        Vp = np.zeros(P.shape(), dtype=dtype)
+        dp.bring_back()
+        orc.prolong(Cl, Vc, P, Vp)
+        lib.prolong(dc, dp, method)
+        assert bits_equal(dp.download(), Vp), ("prolong", desc)
+    finally:
+        dp.close()
+        dc.close()
+
+
+def main():
+    cases = int(sys.argv[1]) if len(sys.argv) > 1 else 200
+    seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
+    global one_case
+    if len(sys.argv) > 3 and sys.argv[3] == "transfers":
+        one_case = one_transfer
+    rng = np.random.default_rng(seed)
+    ctx = lib.Context(0)
+    t0 = time.time()
+    try:
+        for i in range(cases):
+            one_case(ctx, rng, i)
+            if i % 10 == 9:
+                print(f"{i + 1} cases ok, {time.time() - t0:.0f} s", flush=True)
+    finally:
+        ctx.close()
+    print(f"all {cases} cases identical to the oracle (seed {seed})")
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,33 @@
+"""GPU: a short randomised parity run (scripts/fuzz_parity.py: random shapes, boundary conditions, box tables,
+magnitudes, kernels, sweep counts and reductions; random parent/child pairs for the transfers) against the oracle,
+bit for bit.  The script runs thousands of cases on its own; the suite takes a fixed sample of them."""
+import importlib.util
+import os
+
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope="module")
+def fuzz():
+    spec = importlib.util.spec_from_file_location("fuzz_parity", os.path.join(ROOT, "scripts", "fuzz_parity.py"))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    return m
+
+
+@pytest.mark.parametrize("mode,cases,seed", [("sweeps", 150, 11), ("transfers", 150, 12)])
+def test_random_cases_equal_the_oracle(fuzz, mode, cases, seed):
+    from multigrid_amd import lib
+    rng = np.random.default_rng(seed)
+    ctx = lib.Context(0)
+    try:
+        run = fuzz.one_case if mode == "sweeps" else fuzz.one_transfer
+        for i in range(cases):
+            run(ctx, rng, i)
+    finally:
+        ctx.close()
