@@ -1,7 +1,8 @@
 """Randomised parity run on the GPU box: random level shapes, boundary conditions, box tables, relaxation factors,
 magnitudes, kernels and sweep counts; the library's fields, max dV^2 and exact sums against the CPU oracle, bit for
-bit.  Usage: python scripts/fuzz_parity.py [cases] [seed] [transfers]
-(with `transfers`: restriction and prolongation between random pairs of levels instead of sweeps).  Prints one line per 10 cases; stops at the first mismatch
+bit.  Usage: python scripts/fuzz_parity.py [cases] [seed] [transfers|slabs]
+(`transfers`: restriction and prolongation between random pairs of levels instead of sweeps; `slabs`: sweeps of a
+level cut into z slabs, halo planes copied between them, against the oracle's sweeps of the undivided level).  Prints one line per 10 cases; stops at the first mismatch
 with the parameters that reproduce it."""
 import sys
 import time
@@ -137,12 +138,88 @@ def one_transfer(ctx, rng, idx):
         dc.close()
 
 
+def one_slab_case(ctx, rng, idx):
+    """a level cut into two to four z slabs on one GPU (what the ranks of a multi-GPU run hold): every slab swept in
+    one launch or in edge + inner launches, two halo planes per side copied between the slabs after every sweep;
+    fields and reductions against the oracle's sweeps of the undivided level"""
+    import torch
+    from multigrid_amd import slab
+    dims = [3, 8, 17, 64, 65, 129, 140, 257]
+    n = (int(rng.choice(dims)), int(rng.choice(dims[:6])), int(rng.integers(4, 70)))
+    ns = int(rng.integers(2, 5))
+    while n[2] < 2 * ns:
+        ns -= 1
+    while True:                                         # cut points anywhere, every slab at least two planes thick
+        cuts = sorted(int(c) for c in rng.choice(np.arange(2, n[2] - 1), size=ns - 1, replace=False))
+        edges = [0] + cuts + [n[2]]
+        if min(b - a for a, b in zip(edges[:-1], edges[1:])) >= 2:
+            break
+    parts = [(a, b - a) for a, b in zip(edges[:-1], edges[1:])]
+    dtype = np.float64 if rng.integers(0, 2) else np.float32
+    kernel = int(rng.choice([0, 2]))
+    bc = tuple(int(rng.integers(2, 4)) for _ in range(6))
+    sor = float(rng.choice([1.0, 1.5, 1.7]))
+    a = (0.3, 0.3, 0.4)
+    boxes = random_boxes(rng, n, int(rng.choice([0, 1, 3, 6])))
+    desc = dict(idx=idx, n=n, parts=parts, dtype=np.dtype(dtype).name, kernel=kernel, bc=bc, sor=sor, nbox=len(boxes))
+    L = orc.Level(n=n, bc=bc, sor=sor, a=a, boxes=boxes)
+    V = rng.standard_normal(L.shape()).astype(dtype)
+    orc.setup(L, V, False)
+    ctx.set_kernel(kernel)
+    slabs = []
+    try:
+        for z0, k in parts:
+            lv = ctx.level(1, n, dtype, z0, k)
+            lv.set_params(sor, a, bc)
+            lv.set_boxes([b.place for b in boxes], [b.val for b in boxes], [b.rho for b in boxes], [int(b.constant) for b in boxes])
+            lv.upload(V[z0:z0 + k + 2])
+            slabs.append(lv)
+
+        def exchange():
+            ctx.sync()
+            for lo, up in zip(slabs[:-1], slabs[1:]):
+                slab.device_plane_tensor(up, -1, 2).copy_(slab.device_plane_tensor(lo, lo.n3_local - 1, 2))
+                slab.device_plane_tensor(lo, lo.n3_local + 1, 2).copy_(slab.device_plane_tensor(up, 1, 2))
+            torch.cuda.synchronize()
+            for lv in slabs:
+                lv.halo_written()
+
+        exchange()
+        for it in range(4):
+            red = int(rng.choice([0, 1, 3, 3]))
+            e2 = orc.sweep(L, V, orc.ORDER_RB)
+            s, big = orc.abs_sum_exact(L, V)
+            rs = []
+            for lv in slabs:
+                if rng.integers(0, 2):
+                    lv.sweep_part(lib.PART_EDGE, red)
+                    lv.sweep_part(lib.PART_INNER, red)
+                else:
+                    lv.sweep(1, red)
+                if red:
+                    rs.append(lv.result())
+            exchange()
+            if red & 1:
+                assert max(r[0] for r in rs) == e2, ("err", it, desc)
+            if red & 2:
+                assert sum(r[2] for r in rs) == big, ("sum", it, desc)
+            for lv, (z0, k) in zip(slabs, parts):
+                assert bits_equal(np.ascontiguousarray(lv.download()[1:-1]), np.ascontiguousarray(V[z0 + 1:z0 + k + 1])), ("field", it, z0, desc)
+    finally:
+        for lv in slabs:
+            lv.close()
+        ctx.set_kernel(0)
+
+
 def main():
     cases = int(sys.argv[1]) if len(sys.argv) > 1 else 200
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
     global one_case
     if len(sys.argv) > 3 and sys.argv[3] == "transfers":
         one_case = one_transfer
+    if len(sys.argv) > 3 and sys.argv[3] == "slabs":
+        import torch  # noqa: F401  before the HIP library: one HIP runtime per process
+        one_case = one_slab_case
     rng = np.random.default_rng(seed)
     ctx = lib.Context(0)
     t0 = time.time()

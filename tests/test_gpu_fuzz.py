@@ -1,11 +1,13 @@
 """GPU: a short randomised parity run (scripts/fuzz_parity.py: random shapes, boundary conditions, box tables,
-magnitudes, kernels, sweep counts and reductions; random parent/child pairs for the transfers) against the oracle,
+magnitudes, kernels, sweep counts and reductions; random parent/child pairs for the transfers; levels cut into z
+slabs at random planes) against the oracle,
 bit for bit.  The script runs thousands of cases on its own; the suite takes a fixed sample of them."""
 import importlib.util
 import os
 
 import numpy as np
 import pytest
+import torch          # noqa: F401  before the HIP library: one HIP runtime per process
 
 pytestmark = pytest.mark.gpu
 
@@ -20,13 +22,13 @@ def fuzz():
     return m
 
 
-@pytest.mark.parametrize("mode,cases,seed", [("sweeps", 150, 11), ("transfers", 150, 12)])
+@pytest.mark.parametrize("mode,cases,seed", [("sweeps", 150, 11), ("transfers", 150, 12), ("slabs", 80, 13)])
 def test_random_cases_equal_the_oracle(fuzz, mode, cases, seed):
     from multigrid_amd import lib
     rng = np.random.default_rng(seed)
     ctx = lib.Context(0)
     try:
-        run = fuzz.one_case if mode == "sweeps" else fuzz.one_transfer
+        run = {"sweeps": fuzz.one_case, "transfers": fuzz.one_transfer, "slabs": fuzz.one_slab_case}[mode]
         for i in range(cases):
             run(ctx, rng, i)
     finally:
