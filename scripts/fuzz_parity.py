@@ -1,8 +1,9 @@
 """Randomised parity run on the GPU box: random level shapes, boundary conditions, box tables, relaxation factors,
 magnitudes, kernels and sweep counts; the library's fields, max dV^2 and exact sums against the CPU oracle, bit for
-bit.  Usage: python scripts/fuzz_parity.py [cases] [seed] [transfers|slabs]
+bit.  Usage: python scripts/fuzz_parity.py [cases] [seed] [transfers|slabs|solves]
 (`transfers`: restriction and prolongation between random pairs of levels instead of sweeps; `slabs`: sweeps of a
-level cut into z slabs, halo planes copied between them, against the oracle's sweeps of the undivided level).  Prints one line per 10 cases; stops at the first mismatch
+level cut into z slabs, halo planes copied between them, against the oracle's sweeps of the undivided level;
+`solves`: whole bottom-up and V-cycle solves of random input files against the oracle's solve).  Prints one line per 10 cases; stops at the first mismatch
 with the parameters that reproduce it."""
 import sys
 import time
@@ -11,6 +12,9 @@ import numpy as np
 
 from multigrid_amd import lib
 from oracle import oracle as orc
+
+
+STATS = {"compared": 0, "stopped": 0, "not runnable": 0}
 
 
 def random_boxes(rng, n, nbox):
@@ -211,12 +215,90 @@ def one_slab_case(ctx, rng, idx):
         ctx.set_kernel(0)
 
 
+def random_input(rng):
+    """an input file in the reference's format (m_mg_io.F90): a box-shaped cell, one to three boxes (electrodes with a
+    value, dielectric blocks with a density), random mesh, boundary conditions, cycle and transfer methods"""
+    sizes = [16, 24, 32, 40, 48, 56]
+    n = [int(rng.choice(sizes)) for _ in range(3)]
+    cell = [d / 10.0 for d in n]
+    lines = [f"cell {cell[0]} {cell[1]} {cell[2]}", f"max-layers {int(rng.integers(3, 6))}"]
+    nbox = int(rng.integers(1, 4))
+    lines.append(f"boxes {nbox}")
+    if rng.integers(0, 2):
+        lines.append("method w")
+    lines += ["save out.vmg", "begin layers", f"  sor {float(rng.choice([1.0, 1.3, 1.5, 1.6]))}",
+              f"  tol {float(rng.choice([1e-3, 3e-4, 1e-4]))}", f"  v-steps {int(rng.integers(1, 4))}",
+              f"  mesh-size {n[0]} {n[1]} {n[2]}", "  bc all dirichlet"]
+    for ax in "abc":
+        k = int(rng.integers(0, 4))
+        if k:
+            lines.append(f"  bc {ax} {['', 'periodic', 'neumann', 'dirichlet'][k]}")
+    lines += [f"  interp {'half' if rng.integers(0, 2) else 'full'}", "end layers"]
+    for b in range(nbox):
+        llc = [float(rng.uniform(0.05, 0.6)) * c for c in cell]
+        ext = [float(rng.uniform(0.08, 0.35)) * c for c in cell]
+        lines += ["begin box", f"  llc {llc[0]:.4f} {llc[1]:.4f} {llc[2]:.4f}", f"  cell {ext[0]:.4f} {ext[1]:.4f} {ext[2]:.4f}"]
+        if b == 0 or rng.integers(0, 2):
+            lines.append(f"  value {float(rng.choice([1.0, -1.0, 0.5]))}")
+        else:
+            lines += [f"  rho {float(rng.choice([3.0, 0.5, 8.0]))}", "  constant false"]
+        lines.append("end box")
+    return "\n".join(lines) + "\n"
+
+
+def one_solve(ctx_unused, rng, idx):
+    """a whole solve (gs_bottom_up or gs_w with its V cycles, m_gs_CDS.F90) of a random input file: this package's host
+    over the library against the oracle's solve in the same order with the same exact sum; sweep counts, history of
+    every convergence test and the field, bit for bit"""
+    from multigrid_amd import cycle, mgio
+    from tests.helpers import oracle_levels
+    text = random_input(rng)
+    dtype = np.float64 if rng.integers(0, 2) else np.float32
+    kernel = int(rng.choice([0, 1, 2]))
+    opts = dict(device_loop=bool(rng.integers(0, 2)), print_sums=bool(rng.integers(0, 2)))
+    IO = mgio.MgIO(text=text)
+    top = mgio.iomg_read(IO, dtype=dtype)
+    method = mgio.read_method(IO)
+    desc = dict(idx=idx, dtype=np.dtype(dtype).name, kernel=kernel, opts=opts, text=text)
+    if method == cycle.CDS_W_CYCLE and len(list(top.levels())) < 2:
+        STATS["not runnable"] += 1
+        return                             # gs_w needs a child (m_gs_CDS.F90:118): not an input the reference can run
+    try:
+        V, hist, per = orc.solve(oracle_levels(top), method, dtype, order=orc.ORDER_RB, sum_mode=orc.SUM_EXACT, max_sweeps=4000)
+        stopped = bool(np.isnan(hist["sum"]).any())
+    except orc.SolveStopped:
+        stopped = True
+    s = cycle.Solver(top, max_sweeps=4000, **opts)
+    try:
+        s.ctx.set_kernel(kernel)
+        if stopped:
+            try:
+                s.mg_gs_cds(method)
+            except Exception:
+                STATS["stopped"] += 1
+                return                     # a diverging or endless iteration is reported, not compared
+            raise AssertionError(("the oracle stopped, the library did not", desc))
+        s.mg_gs_cds(method)
+        h = s.history_array()
+        keep = hist if opts["print_sums"] else hist[hist["kind"] != 1]
+        assert [l.itt for l in top.levels()] == per, ("counts", [l.itt for l in top.levels()], per, desc)
+        assert len(h) == len(keep), ("history length", len(h), len(keep), desc)
+        for f in ("layer", "kind", "itt", "tol", "sum", "err"):
+            assert np.array_equal(h[f], keep[f]), (f, desc)
+        assert bits_equal(top.dev.download(), V), ("field", desc)
+        STATS["compared"] += 1
+    finally:
+        s.close()
+
+
 def main():
     cases = int(sys.argv[1]) if len(sys.argv) > 1 else 200
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
     global one_case
     if len(sys.argv) > 3 and sys.argv[3] == "transfers":
         one_case = one_transfer
+    if len(sys.argv) > 3 and sys.argv[3] == "solves":
+        one_case = one_solve
     if len(sys.argv) > 3 and sys.argv[3] == "slabs":
         import torch  # noqa: F401  before the HIP library: one HIP runtime per process
         one_case = one_slab_case
@@ -226,11 +308,11 @@ def main():
     try:
         for i in range(cases):
             one_case(ctx, rng, i)
-            if i % 10 == 9:
+            if i % 10 == 9 or one_case is one_solve:
                 print(f"{i + 1} cases ok, {time.time() - t0:.0f} s", flush=True)
     finally:
         ctx.close()
-    print(f"all {cases} cases identical to the oracle (seed {seed})")
+    print(f"all {cases} cases identical to the oracle (seed {seed})" + (f" {STATS}" if one_case is one_solve else ""))
 
 
 if __name__ == "__main__":
