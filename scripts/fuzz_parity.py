@@ -1,9 +1,10 @@
 """Randomised parity run on the GPU box: random level shapes, boundary conditions, box tables, relaxation factors,
 magnitudes, kernels and sweep counts; the library's fields, max dV^2 and exact sums against the CPU oracle, bit for
-bit.  Usage: python scripts/fuzz_parity.py [cases] [seed] [transfers|slabs|solves]
+bit.  Usage: python scripts/fuzz_parity.py [cases] [seed] [transfers|slabs|solves|boxes]
 (`transfers`: restriction and prolongation between random pairs of levels instead of sweeps; `slabs`: sweeps of a
 level cut into z slabs, halo planes copied between them, against the oracle's sweeps of the undivided level;
-`solves`: whole bottom-up and V-cycle solves of random input files against the oracle's solve).  Prints one line per 10 cases; stops at the first mismatch
+`solves`: whole bottom-up and V-cycle solves of random input files against the oracle's solve; `boxes`: the device's
+search for the cells of a box against the oracle's).  Prints one line per 10 cases; stops at the first mismatch
 with the parameters that reproduce it."""
 import sys
 import time
@@ -291,12 +292,38 @@ def one_solve(ctx_unused, rng, idx):
         s.close()
 
 
+def one_box_place(ctx, rng, idx):
+    """grid_add_box's search for the cells a box holds (t_mg.f90:359-395) on the device against the oracle: skewed
+    and orthogonal lattices, boxes inside, across and outside the cell, corners exactly on lattice points"""
+    n = tuple(int(rng.integers(1, 70)) for _ in range(3))
+    if rng.integers(0, 2):
+        cell = np.diag(rng.uniform(1.0, 4.0, 3)) + rng.uniform(-0.4, 0.4, (3, 3))
+    else:
+        cell = np.diag([float(d) * float(rng.choice([0.1, 0.125, 0.3])) for d in n])
+    dL = cell / np.array(n, dtype=np.float64)[None, :]
+    off = rng.uniform(-0.5, 0.5, 3) if rng.integers(0, 2) else np.zeros(3)
+    ext = np.abs(cell).sum(axis=1)
+    for _ in range(8):
+        if rng.integers(0, 2):       # corners on lattice points: the comparisons of the search meet equality
+            i0 = np.array([int(rng.integers(-2, d + 2)) for d in n], dtype=np.float64)
+            i1 = np.array([int(rng.integers(0, d + 3)) for d in n], dtype=np.float64)
+            llc = off + dL @ i0
+            bcell = dL * i1[None, :]
+        else:
+            llc = off + rng.uniform(-0.6, 0.9, 3) * ext
+            bcell = np.diag(rng.uniform(-0.3, 0.7, 3) * ext) + rng.uniform(-0.05, 0.05, (3, 3))
+        got, want = ctx.box_place(n, dL, off, llc, bcell), orc.box_place(n, dL, off, llc, bcell)
+        assert np.array_equal(got, want), ("box_place", idx, n, dL.tolist(), off.tolist(), llc.tolist(), bcell.tolist(), got, want)
+
+
 def main():
     cases = int(sys.argv[1]) if len(sys.argv) > 1 else 200
     seed = int(sys.argv[2]) if len(sys.argv) > 2 else 1
     global one_case
     if len(sys.argv) > 3 and sys.argv[3] == "transfers":
         one_case = one_transfer
+    if len(sys.argv) > 3 and sys.argv[3] == "boxes":
+        one_case = one_box_place
     if len(sys.argv) > 3 and sys.argv[3] == "solves":
         one_case = one_solve
     if len(sys.argv) > 3 and sys.argv[3] == "slabs":
