@@ -219,8 +219,11 @@ def one_slab_case(ctx, rng, idx):
 def random_input(rng):
     """an input file in the reference's format (m_mg_io.F90): a box-shaped cell, one to three boxes (electrodes with a
     value, dielectric blocks with a density), random mesh, boundary conditions, cycle and transfer methods"""
-    sizes = [16, 24, 32, 40, 48, 56]
-    n = [int(rng.choice(sizes)) for _ in range(3)]
+    sizes = [24, 40, 41, 44, 48, 50, 64, 80, 81]      # from 40 cells on a direction is halved (t_mg.f90:183-201)
+    while True:
+        n = [int(rng.choice(sizes)) for _ in range(3)]
+        if n[0] * n[1] * n[2] <= 160000:
+            break
     cell = [d / 10.0 for d in n]
     lines = [f"cell {cell[0]} {cell[1]} {cell[2]}", f"max-layers {int(rng.integers(3, 6))}"]
     nbox = int(rng.integers(1, 4))

@@ -22,7 +22,7 @@ def fuzz():
     return m
 
 
-@pytest.mark.parametrize("mode,cases,seed", [("sweeps", 150, 11), ("transfers", 150, 12), ("slabs", 80, 13), ("solves", 40, 14), ("boxes", 200, 15)])
+@pytest.mark.parametrize("mode,cases,seed", [("sweeps", 150, 11), ("transfers", 150, 12), ("slabs", 80, 13), ("solves", 20, 14), ("boxes", 200, 15)])
 def test_random_cases_equal_the_oracle(fuzz, mode, cases, seed):
     from multigrid_amd import lib
     rng = np.random.default_rng(seed)
