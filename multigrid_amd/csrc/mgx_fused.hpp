@@ -68,6 +68,7 @@ struct MgxBoxLds {           // per-block copy of what the box logic needs
   T wtab[2][64][6];
   uint4 xq[64 + 4];          // X sets of positions xs-1 .. xs+2 around staged pair column pc (up to two halo pairs a side)
   uint4 yq[64];              // Y sets of rows y-1, y, y+1 around staged row r (rows past the tile: empty)
+  unsigned big;              // a lane of the block met a |V| beyond the fast range of the partial sums
 };
 
 template <int R> struct MgxCodes { unsigned c[R]; };   // per pair: low half = black cell of plane k, high half = red cell of plane k-1
@@ -185,6 +186,12 @@ __device__ __forceinline__ void mgx_stream_store(const mgx_f2v v, mgx_f2v *ptr) 
 __device__ __forceinline__ double mgx_max_abs(double m, double d) { return __builtin_fmax(m, __builtin_fabs(d)); }
 __device__ __forceinline__ float mgx_max_abs(float m, float d) { return __builtin_fmaxf(m, __builtin_fabsf(d)); }
 
+// |v| as an unsigned integer that orders like |v| (NaN above everything): the high word of a double, the bits of a
+// float; MGX_FAST_SUM_LIMIT_HI / _F32 are the fast limit 2048 in the two forms
+#define MGX_FAST_SUM_LIMIT_F32 0x45000000u
+__device__ __forceinline__ unsigned mgx_abs_top(const double v) { return (unsigned)__double2hiint(v) & 0x7fffffffu; }
+__device__ __forceinline__ unsigned mgx_abs_top(const float v) { return __float_as_uint(v) & 0x7fffffffu; }
+
 // branch-free form of mgx_exact_add (same integer result: a value with bits below the grid of the sum is rounded
 // to nearest, ties to even, exactly as there and as in the two-double partial sums)
 __device__ inline void mgx_exact_add_nb(u64 &lo, u64 &hi, double a, unsigned &ovf) {
@@ -203,6 +210,29 @@ __device__ inline void mgx_exact_add_nb(u64 &lo, u64 &hi, double a, unsigned &ov
   const u64 ahi = sh >= 0 ? ((m >> 1) >> (63 - shl)) : 0ull;
   lo += alo;
   hi += ahi + (lo < alo ? 1ull : 0ull);
+}
+
+// Exact sum of |V| over the cells x0..x1, y0..y1, planes z0..z1 (local) of the field a block has just stored: the
+// rare way out for a block that met a value beyond the fast range of its partial sums.  Every thread of the block
+// calls it; the block's stores are waited for first.
+template <typename T>
+__device__ __forceinline__ void mgx_block_exact_sum(const T *__restrict__ dst, const MgxGeom &g, const int x0, const int x1,
+                                                 const int y0, const int y1, const int z0, const int z1, u64 &lo, u64 &hi,
+                                                 unsigned &ovf) {
+  __threadfence();
+  __syncthreads();
+  const int nx = x1 - x0 + 1, ny = y1 - y0 + 1, nz = z1 - z0 + 1;
+  if (nx <= 0 || ny <= 0 || nz <= 0) return;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nwaves = blockDim.x >> 6;
+  for (int zy = wave; zy < nz * ny; zy += nwaves) {          // one row per wave at a time
+    const int z = z0 + zy / ny, y = y0 + zy % ny;
+    const T *row = dst + g.pz * (long long)(z + 1) + g.front + (long long)g.px * y - 1;
+    for (int x = x0 + lane; x <= x1; x += 64) {
+      // (nothing in this launch has read the field being written before: no stale line in any cache)
+      const double v = (double)row[x];
+      mgx_exact_add(lo, hi, v < 0.0 ? -v : v, ovf);
+    }
+  }
 }
 
 // P0 and HALO specialise the body per wave.  With x-pairs starting at an odd x, the odd ("black") cell of a
@@ -371,6 +401,7 @@ __device__ __forceinline__ void mgx_fused_body(const T *__restrict__ src, T *__r
   int sk = 0;                      // LDS slot of plane k; k-1 lives in sk-1, k+1 in sk+1 (mod 3)
   MGX_STAGE(sk, 1, 0)              // set 1 = plane zc0-1 = plane k of the first step (unroll position 0)
   make_zsets(zc0 - 1 + g.z0, (zc0 - 1) & 1);
+  if (threadIdx.x == 0) bl->big = 0u;
   MGX_SYNC();
   unsigned xyany = 0u;                   // boxes that can contain a cell of this lane's pairs, or a neighbour of one
   unsigned codes[2][R];                  // box codes of the pairs, per step parity; valid for the Z sets in `key`
@@ -397,29 +428,27 @@ __device__ __forceinline__ void mgx_fused_body(const T *__restrict__ src, T *__r
   u64 slo = 0, shi = 0;
   double fh = 0.0, fl2 = 0.0;      // exact partial sums of this lane, moved into (slo, shi) every NSET planes
   unsigned ovf = 0;
+  unsigned topmax = 0u;            // largest high word of a counted |V|
   unsigned zmm = 0u;               // Z set of plane k-2
   static_assert(2 * RW * NSET <= MGX_FAST_SUM_CELLS, "partial sums must stay exact between two flushes");
-  // |V| of R cells into the sum: two-double partial sums while every value is below the fast limit (the
-  // branch is uniform and practically never taken), the integer path otherwise.  A cell that does not count
-  // gets the high word of |V| cleared: what is left is below 2^-1022 and adds exactly nothing to either
-  // partial sum, one 32-bit select instead of a 64-bit one; the limit test is one integer compare on the
-  // largest high word.
+  // |V| of R cells into the sum: two-double partial sums, exact while every value is below the fast limit.  A cell
+  // that does not count gets the high word of |V| cleared: what is left is below 2^-1022 and adds exactly nothing
+  // to either partial sum, one 32-bit select instead of a 64-bit one.  The largest high word a lane has met is kept
+  // (one integer maximum per cell) and looked at once, after the march: a block in which any counted value was not
+  // below the limit (too large, infinite, not a number) throws its partial sums away and adds up the cells it has
+  // just stored with the integer path (mgx_block_exact_sum).  No test in the plane loop: a wave-wide branch per
+  // phase cost 6 us of a 450 us sweep at 512^3.
 #define MGX_SUM_R(val, cond)                                                           \
   {                                                                                    \
     double a_[R];                                                                      \
-    unsigned top_ = 0u;                                                                \
     _Pragma("unroll") for (int j = 0; j < R; ++j) {                                    \
       const double v_ = (double)(val);                                                 \
       const unsigned h_ = (cond) ? ((unsigned)__double2hiint(v_) & 0x7fffffffu) : 0u;  \
       a_[j] = __hiloint2double((int)h_, __double2loint(v_));                           \
-      top_ = h_ > top_ ? h_ : top_;                                                    \
+      const unsigned t_ = sizeof(T) == 8 ? h_ : ((cond) ? mgx_abs_top(val) : 0u);      \
+      topmax = t_ > topmax ? t_ : topmax;                                              \
     }                                                                                  \
-    if (__builtin_expect(__any(top_ >= MGX_FAST_SUM_LIMIT_HI), 0)) {                   \
-      _Pragma("unroll") for (int j = 0; j < R; ++j)                                    \
-        mgx_exact_add_nb(slo, shi, (cond) ? a_[j] : 0.0, ovf);                         \
-    } else {                                                                           \
-      _Pragma("unroll") for (int j = 0; j < R; ++j) mgx_fast_sum_add(fh, fl2, a_[j]);  \
-    }                                                                                  \
+    _Pragma("unroll") for (int j = 0; j < R; ++j) mgx_fast_sum_add(fh, fl2, a_[j]);    \
   }
   // rows of the tile proper (the grown ring belongs to the neighbouring tiles' reductions): uniform per wave
   bool rowin[R];
@@ -577,6 +606,15 @@ __device__ __forceinline__ void mgx_fused_body(const T *__restrict__ src, T *__r
 #undef MGX_STAGE
 #undef MGX_Q
 
+  if (reduce & 2) {                // uniform over the block
+    if (topmax >= (sizeof(T) == 8 ? MGX_FAST_SUM_LIMIT_HI : MGX_FAST_SUM_LIMIT_F32)) bl->big = 1u;
+    __syncthreads();
+    if (bl->big != 0u) {            // the same word for every lane
+      slo = 0;
+      shi = 0;
+      mgx_block_exact_sum<T>(dst, g, tx0, min(tx0 + 127, g.n1), ty0, min(ty0 + TY - 1, g.n2), zc0, zc1, slo, shi, ovf);
+    }
+  }
   if (reduce) mgx_block_commit<NW + 1>((double)(err * err), slo, shi, ovf, reduce, res, n_commit);
 }
 

@@ -37,23 +37,13 @@
 #define MGX_TB_SYNC() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
 #endif
 
+// |V| of R cells into the two-double partial sums; a[j] already has its high word cleared where the cell does not
+// count (adds exactly nothing).  Whether every value was inside the fast range is looked at once, after the march
+// (see mgx_fused_body).
 template <int R>
-__device__ __forceinline__ void mgx_sum_items(const double (&a)[R], double &fh, double &fl2, u64 &slo, u64 &shi,
-                                              unsigned &ovf) {
-  // a[j] already has its high word cleared where the cell does not count (adds exactly nothing)
-  unsigned top = 0u;
+__device__ __forceinline__ void mgx_sum_items(const double (&a)[R], double &fh, double &fl2) {
 #pragma unroll
-  for (int j = 0; j < R; ++j) {
-    const unsigned h = (unsigned)__double2hiint(a[j]);
-    top = h > top ? h : top;
-  }
-  if (__builtin_expect(__any(top >= MGX_FAST_SUM_LIMIT_HI), 0)) {
-#pragma unroll
-    for (int j = 0; j < R; ++j) mgx_exact_add_nb(slo, shi, a[j], ovf);
-  } else {
-#pragma unroll
-    for (int j = 0; j < R; ++j) mgx_fast_sum_add(fh, fl2, a[j]);
-  }
+  for (int j = 0; j < R; ++j) mgx_fast_sum_add(fh, fl2, a[j]);
 }
 
 // |v| where the cell counts, else a value below 2^-1022 (high word cleared)
@@ -215,6 +205,7 @@ __device__ __forceinline__ void mgx_tb_body(const T *__restrict__ src, T *__rest
   for (int i = 0; i <= L; ++i)
 #pragma unroll
     for (int j = 0; j < R; ++j) cc[i][j] = 0u;
+  if (threadIdx.x == 0) bl->big = 0u;
   __syncthreads();
   if (BOXES) {
     const uint4 xs4 = bl->xq[pcs];
@@ -238,6 +229,7 @@ __device__ __forceinline__ void mgx_tb_body(const T *__restrict__ src, T *__rest
   u64 slo = 0, shi = 0;
   double fh = 0.0, fl2 = 0.0;
   unsigned ovf = 0;
+  unsigned topmax = 0u;                          // largest |V| counted so far, as mgx_abs_top gives it
   bool rowin[R];
 #pragma unroll
   for (int j = 0; j < R; ++j) {
@@ -335,9 +327,12 @@ __device__ __forceinline__ void mgx_tb_body(const T *__restrict__ src, T *__rest
               const int q = MGX_TBQ(U, j);
               const bool urow = zown && rowin[j];
               if (urow) err = mgx_max_abs(err, cnew[j] - vold[j]);   // 0 where nothing was updated
-              a_[j] = mgx_abs_if((double)cnew[j], urow && (FREE || (fl[j] & (1u << (16 + q))) != 0u));
+              const bool counts = urow && (FREE || (fl[j] & (1u << (16 + q))) != 0u);
+              a_[j] = mgx_abs_if((double)cnew[j], counts);
+              const unsigned t_ = counts ? mgx_abs_top(cnew[j]) : 0u;
+              topmax = t_ > topmax ? t_ : topmax;
             }
-            if (reduce & 2) mgx_sum_items<R>(a_, fh, fl2, slo, shi, ovf);
+            if (reduce & 2) mgx_sum_items<R>(a_, fh, fl2);
           }
         }
       }
@@ -394,6 +389,15 @@ __device__ __forceinline__ void mgx_tb_body(const T *__restrict__ src, T *__rest
   }
 #undef MGX_TBQ
 #undef MGX_CMP
+  if (reduce & 2) {                              // uniform over the block
+    if (topmax >= (sizeof(T) == 8 ? MGX_FAST_SUM_LIMIT_HI : MGX_FAST_SUM_LIMIT_F32)) bl->big = 1u;
+    __syncthreads();
+    if (bl->big != 0u) {                         // the same word for every lane
+      slo = 0;
+      shi = 0;
+      mgx_block_exact_sum<T>(dst, g, tx0, min(tx0 + 2 * TXP - 1, g.n1), ty0, min(ty0 + TY - 1, g.n2), zc0, zc1, slo, shi, ovf);
+    }
+  }
   if (reduce & 3) mgx_block_commit<NW + 1>((double)(err * err), slo, shi, ovf, reduce & 3, res, n_commit);
 }
 
