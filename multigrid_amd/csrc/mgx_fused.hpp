@@ -430,7 +430,11 @@ __device__ __forceinline__ void mgx_fused_body(const T *__restrict__ src, T *__r
   unsigned ovf = 0;
   unsigned topmax = 0u;            // largest high word of a counted |V|
   unsigned zmm = 0u;               // Z set of plane k-2
-  static_assert(2 * RW * NSET <= MGX_FAST_SUM_CELLS, "partial sums must stay exact between two flushes");
+#ifndef MGX_FLUSH_GROUPS
+#define MGX_FLUSH_GROUPS 8
+#endif
+  static_assert(2 * RW * NSET * MGX_FLUSH_GROUPS <= MGX_FAST_SUM_CELLS, "partial sums must stay exact between two flushes");
+  int turns = 0;
   // |V| of R cells into the sum: two-double partial sums, exact while every value is below the fast limit.  A cell
   // that does not count gets the high word of |V| cleared: what is left is below 2^-1022 and adds exactly nothing
   // to either partial sum, one 32-bit select instead of a 64-bit one.  The largest high word a lane has met is kept
@@ -595,8 +599,10 @@ __device__ __forceinline__ void mgx_fused_body(const T *__restrict__ src, T *__r
       zmm = zm;                                             // Z set of plane k-1 = (k+1)-2 for the next red phase
       MGX_SYNC();
     }
-    if (!HALO && (reduce & 2)) mgx_fast_sum_flush(fh, fl2, slo, shi);
+    // the partial sums move into the integer every MGX_FLUSH_GROUPS turns of the unrolled loop
+    if (!HALO && (reduce & 2) && (++turns % MGX_FLUSH_GROUPS) == 0) mgx_fast_sum_flush(fh, fl2, slo, shi);
   }
+  if (!HALO && (reduce & 2)) mgx_fast_sum_flush(fh, fl2, slo, shi);
 #undef MGX_SUM_R
 #undef MGX_FETCH
 #undef MGX_BLK

@@ -381,12 +381,15 @@ __device__ __forceinline__ void mgx_tb_body(const T *__restrict__ src, T *__rest
     }
   };
 
+  static_assert(2 * 2 * R * MGX_FLUSH_GROUPS <= MGX_FAST_SUM_CELLS, "partial sums must stay exact between two flushes");
+  int turns = 0;
 #pragma clang loop unroll(disable)
   for (int kb = k0; kb <= zc1 + L; kb += 2) {
     step(std::integral_constant<int, 0>{}, kb);
     if (kb + 1 <= zc1 + L) step(std::integral_constant<int, 1>{}, kb + 1);
-    if (!HALO && (reduce & 2)) mgx_fast_sum_flush(fh, fl2, slo, shi);
+    if (!HALO && (reduce & 2) && (++turns % MGX_FLUSH_GROUPS) == 0) mgx_fast_sum_flush(fh, fl2, slo, shi);
   }
+  if (!HALO && (reduce & 2)) mgx_fast_sum_flush(fh, fl2, slo, shi);
 #undef MGX_TBQ
 #undef MGX_CMP
   if (reduce & 2) {                              // uniform over the block
