@@ -90,6 +90,9 @@ __host__ __device__ inline void mgx_exact_add(u64 &lo, u64 &hi, double a, unsign
 #define MGX_FAST_SUM_LIMIT 2048.0
 #define MGX_FAST_SUM_LIMIT_HI 0x40A00000u        /* high word of 2048.0: |v| >= 2048 or not finite <=> high word of |v| >= this */
 #define MGX_FAST_SUM_CELLS 1023
+#ifndef MGX_FLUSH_GROUPS
+#define MGX_FLUSH_GROUPS 8                       /* turns of a sweep kernel's plane loop between two flushes */
+#endif
 
 __device__ inline void mgx_fast_sum_add(double &h, double &l, const double a) {
   const double c1 = 1048576.0;                       // 2^20

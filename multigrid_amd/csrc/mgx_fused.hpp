@@ -426,13 +426,10 @@ __device__ __forceinline__ void mgx_fused_body(const T *__restrict__ src, T *__r
 
   T err = (T)0;                    // max |vv - V|, squared once at the end (rounding is monotone: same bits)
   u64 slo = 0, shi = 0;
-  double fh = 0.0, fl2 = 0.0;      // exact partial sums of this lane, moved into (slo, shi) every NSET planes
+  double fh = 0.0, fl2 = 0.0;      // exact partial sums of this lane, moved into (slo, shi) every few turns of the loop
   unsigned ovf = 0;
   unsigned topmax = 0u;            // largest high word of a counted |V|
   unsigned zmm = 0u;               // Z set of plane k-2
-#ifndef MGX_FLUSH_GROUPS
-#define MGX_FLUSH_GROUPS 8
-#endif
   static_assert(2 * RW * NSET * MGX_FLUSH_GROUPS <= MGX_FAST_SUM_CELLS, "partial sums must stay exact between two flushes");
   int turns = 0;
   // |V| of R cells into the sum: two-double partial sums, exact while every value is below the fast limit.  A cell
