@@ -532,7 +532,8 @@ __device__ __forceinline__ void mgx_fused_body(const T *__restrict__ src, T *__r
           for (int j = 0; j < R; ++j) {
             const bool urow = zown && rowin[j];
             actv[j] = actv[j] && urow;
-            if (urow) err = mgx_max_abs(err, cnew[j] - vold[j]);
+            const T d_ = cnew[j] - vold[j];             // a select, not a branch: the phase stays one block of code
+            err = mgx_max_abs(err, urow ? d_ : (T)0);
           }
           if (reduce & 2) MGX_SUM_R(cnew[j], actv[j])
         }
@@ -582,8 +583,10 @@ __device__ __forceinline__ void mgx_fused_body(const T *__restrict__ src, T *__r
         }
         if (reduce) {
 #pragma unroll
-          for (int j = 0; j < R; ++j)
-            if (!FREE || rowin[j]) err = mgx_max_abs(err, rnew[j] - vold[j]);   // not FREE: 0 where nothing was updated
+          for (int j = 0; j < R; ++j) {
+            const T d_ = rnew[j] - vold[j];             // not FREE: 0 where nothing was updated
+            err = mgx_max_abs(err, (!FREE || rowin[j]) ? d_ : (T)0);
+          }
           if (reduce & 2) MGX_SUM_R(rnew[j], actv[j])
         }
       }
