@@ -326,7 +326,8 @@ __device__ __forceinline__ void mgx_tb_body(const T *__restrict__ src, T *__rest
             for (int j = 0; j < R; ++j) {
               const int q = MGX_TBQ(U, j);
               const bool urow = zown && rowin[j];
-              if (urow) err = mgx_max_abs(err, cnew[j] - vold[j]);   // 0 where nothing was updated
+              const T d_ = cnew[j] - vold[j];                        // 0 where nothing was updated
+              err = mgx_max_abs(err, urow ? d_ : (T)0);              // a select, not a branch per row
               const bool counts = urow && (FREE || (fl[j] & (1u << (16 + q))) != 0u);
               a_[j] = mgx_abs_if((double)cnew[j], counts);
               const unsigned t_ = counts ? mgx_abs_top(cnew[j]) : 0u;
