@@ -218,6 +218,56 @@ def cpu_baseline(seconds_target: float = 12.0, n=(512, 512, 512)):
                 sample=f"{k} red-black sweeps of the C oracle (1 thread) on {n[0]}x{n[1]}x{n[2]}, {t:.1f} s")
 
 
+def vcycle_cpu_baseline(ctx, n=80, tol="1.e-8", sor="1.7"):
+    """The first-named metric beside a CPU figure: the reference's own `mg` program (oracle/_ref/mg_ref_omp_O3_f64: its
+    parser, hierarchy, cycle control and OpenMP smoother, real(8) build) solving the config-3 input `method v-cycle` to
+    `tol` at n^3 — the size it finishes inside the bench's budget — on every core this process may use, and the same
+    input file solved on the GPU.  The reference sweeps in its own (racy under OpenMP) order, the GPU in red-black
+    order: sweep counts are reported for both."""
+    import re
+    from multigrid_amd import cycle, mgio
+    text = config3_input((n, n, n), tol=tol, sor=sor)
+    out = {"workload": f"config 3 at {n}x{n}x{n}, method v-cycle, tol {tol}, sor {sor}, v-steps 2"}
+    exe = os.path.join(ROOT, "oracle", "_ref", "mg_ref_omp_O3_f64")
+    cores = host_cores()
+    if os.path.exists(exe):
+        try:
+            with tempfile.TemporaryDirectory() as td:
+                with open(os.path.join(td, "mg.input"), "w") as f:
+                    f.write(text)
+                t0 = time.perf_counter()
+                r = subprocess.run([exe, "mg.input"], cwd=td, env=dict(os.environ, OMP_NUM_THREADS=str(cores)),
+                                   stdout=subprocess.PIPE, stderr=subprocess.STDOUT, universal_newlines=True, timeout=900)
+                t = time.perf_counter() - t0
+            done = re.findall(r"Completed:\s*(\d+):\s*(\d+) in\s+(\d+) itt", r.stdout)
+            out["cpu"] = {"seconds": t, "cores": cores, "kind": "reference", "returncode": r.returncode,
+                          "program": "the reference's mg (amdflang -O3 -fopenmp, real(8) build), whole program incl. input and .VMG output",
+                          "sweeps_on_upper_level_per_pair": {f"{a}:{b}": int(k) for a, b, k in done}}
+        except Exception as e:
+            out["cpu"] = {"seconds": None, "error": str(e)}
+    else:
+        out["cpu"] = {"seconds": None, "error": "oracle/_ref/mg_ref_omp_O3_f64 is not built"}
+    top = mgio.iomg_read(mgio.MgIO(text=text))
+    solver = cycle.Solver(top, ctx=ctx, print_sums=False, max_sweeps=400000)
+    try:
+        import torch
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        status = "converged"
+        try:
+            solver.mg_gs_cds(cycle.CDS_W_CYCLE)
+        except Exception as e:
+            status = f"stopped: {e}"
+        torch.cuda.synchronize()
+        out["gpu"] = {"seconds": time.perf_counter() - t0, "status": status,
+                      "sweeps_per_level": [int(g.itt) for g in top.levels()]}
+    finally:
+        solver.close()
+    if out["cpu"].get("seconds") and out["gpu"]["status"] == "converged":
+        out["speedup"] = out["cpu"]["seconds"] / out["gpu"]["seconds"]
+    return out
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -306,7 +356,7 @@ def main():
         local_cells = total_cells = n ** 3
         workload = (f"config 3: {n}x{n}x{n} mixed periodic/Neumann/Dirichlet, 2 plate electrodes + rho=3 block, "
                     f"finest level, one red-black SOR sweep with fused err/sum reductions per step")
-        scaling = "weak"
+        scaling = "strong"      # (one GPU: nothing scales; the multi-GPU runs of this bench keep the total work fixed)
     else:
         from multigrid_amd import slab
         cfg = args.config or 5
@@ -501,6 +551,9 @@ def main():
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         progress("CPU baseline: the reference's smoother on the host cores")
         out["cpu_baseline"] = cpu_baseline()
+        if not args.no_vcycle:
+            progress("CPU baseline of the V-cycle: the reference's mg program on a size it finishes in the budget")
+            out["vcycle_cpu_baseline"] = vcycle_cpu_baseline(ctx)
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:

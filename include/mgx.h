@@ -87,8 +87,10 @@ int mgx_ctx_info(mgx_ctx *ctx, int *device, void **stream);
  * the state it leaves: mgx_graph_launch enqueues one repetition on the context's stream if the levels are in the
  * former (MGX_ESTATE otherwise: record another graph from this state, or call the routines one by one) and puts them
  * into the latter.  A cycle that sweeps a level an odd number of passes alternates between two states and needs two
- * graphs.  _end with out == NULL drops the recording.  No counterpart in the reference (its loop calls the routines
- * one by one). */
+ * graphs.  _end with out == NULL drops the recording.  A graph also carries the box tables, tile lists and sweep
+ * parameters of its levels as they were when it was recorded: after mgx_level_set_boxes or mgx_level_set_params on one
+ * of them (or when a level was destroyed) mgx_graph_launch returns MGX_ESTATE and the sequence must be recorded again.
+ * No counterpart in the reference (its loop calls the routines one by one). */
 typedef struct mgx_graph mgx_graph;
 int mgx_ctx_capture_begin(mgx_ctx *ctx);
 int mgx_ctx_capture_end(mgx_ctx *ctx, mgx_graph **out);

@@ -5,7 +5,9 @@ solve on the GPU, write the `save` files (default mg.vmg).  Files are the binary
 is not `cube` is binary; `vmgasc` is shadowed by `vmg`), and the cube writer is not part of this package.
 `--double` runs in real(8) (the reference as shipped is real(4), t_mg.f90:8).  `--reference-order` sweeps in the
 reference's own order (gs, m_gs_CDS.F90:317-345) instead of red-black: the results of the reference on one thread,
-bit for bit in real(8), at any over-relaxation, many times slower."""
+bit for bit in real(8), at any over-relaxation, several times slower.  Without a flag that order is selected by itself
+for `method v-cycle` inputs whose over-relaxation the red-black ordering does not take (sor > 1.7; the parser's
+default 1.8, m_mg_io.F90:87, among them), with one line on stderr; `--red-black` keeps the red-black kernels."""
 from __future__ import annotations
 
 import sys
@@ -28,19 +30,17 @@ def mg_save(top: G.MgGrid, filename: str, V: np.ndarray) -> str:
 def main(argv=None) -> int:
     argv = sys.argv[1:] if argv is None else argv
     precision = np.float64 if "--double" in argv else np.float32
-    reference_order = "--reference-order" in argv
+    order = (cycle.ORDER_REFERENCE if "--reference-order" in argv else
+             cycle.ORDER_RED_BLACK if "--red-black" in argv else cycle.ORDER_AUTO)
     argv = [a for a in argv if not a.startswith("--")]
     filein = argv[-1] if argv else "mg.input"        # the last argument, as in mg.F90:60-66
     IO = mgio.MgIO(path=filein)
     top = mgio.iomg_read(IO, dtype=precision)
     method = mgio.read_method(IO)
-    if not reference_order and method == cycle.CDS_W_CYCLE and any(float(g.sor) > cycle.RB_SOR_LIMIT for g in top.levels()):
+    if order == cycle.ORDER_RED_BLACK and method == cycle.CDS_W_CYCLE and any(float(g.sor) > cycle.RB_SOR_LIMIT for g in top.levels()):
         print("warning: `method v-cycle` with sor > 1.7." + cycle.divergence_hint(max(float(g.sor) for g in top.levels())),
               file=sys.stderr)
-    solver = cycle.Solver(top, verbose=True)
-    if reference_order:
-        from . import lib
-        solver.ctx.set_kernel(lib.KERNEL_LEX)
+    solver = cycle.Solver(top, verbose=True, order=order)
     try:
         names = mgio.save_names(IO, "init-save")
         if names:

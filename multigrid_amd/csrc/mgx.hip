@@ -58,10 +58,10 @@ extern "C" const char *mgx_version(void) { return "mgx 0.1 (gfx950)"; }
 #define MGX_NOALLOC_REC 8
 #define MGX_NOALLOC_MAX_BLOCKS 8192
 #define MGX_NOALLOC_ROWS_PER_BLOCK 64
-#define MGX_MAX_DEVICES 64
 static __device__ __align__(256) u64 scratch[MGX_NOALLOC_MAX_BLOCKS * MGX_NOALLOC_REC];   // 512 KiB
 static u64 *g_scratch_ptr[MGX_MAX_DEVICES] = {nullptr};
 
+static unsigned long long g_level_uid = 0;   // the next level's uid
 static int mgx_lex_tiled = 1;    // the reference-order sweep by tile hyperplanes (1) or by cell hyperplanes (0)
 static int mgx_pair_pass = -1;   // 0: never two sweeps per pass, 1: wherever the kernel applies, -1: where it pays (default)
 
@@ -88,6 +88,10 @@ struct mgx_ctx {
 struct mgx_level {
   mgx_ctx *ctx = nullptr;
   int layer = 0;
+  // what a recorded graph bakes into its kernel arguments beyond the buffers: the box table, the tile lists, sor, a, bc.
+  // `epoch` counts every change of those (mgx_level_set_params, mgx_level_set_boxes, a rebuilt tile list); `uid` tells
+  // a level from a later one that malloc put at the same address.
+  unsigned long long uid = 0, epoch = 0;
   int elem = 8;
   MgxGeom g{};
   long long elems = 0;         // allocated elements per buffer
@@ -284,6 +288,7 @@ struct mgx_graph {
   hipGraphExec_t exec = nullptr;
   std::vector<mgx_level *> levels;
   std::vector<MgxLevelState> from, to;
+  std::vector<unsigned long long> uid, epoch;   // of `levels` when the recording ended
 };
 
 static MgxLevelState level_state(const mgx_level *lv);
@@ -328,6 +333,7 @@ extern "C" int mgx_ctx_capture_end(mgx_ctx *ctx, mgx_graph **out) {
   g->levels = ctx->levels;
   g->from = ctx->snapshot;
   g->to = to;
+  for (const mgx_level *lv : ctx->levels) { g->uid.push_back(lv->uid); g->epoch.push_back(lv->epoch); }
   e = hipGraphInstantiate(&g->exec, graph, nullptr, nullptr, 0);
   if (e != hipSuccess) {
     (void)hipGraphDestroy(graph);
@@ -343,6 +349,12 @@ extern "C" int mgx_graph_launch(mgx_graph *g) {
   mgx_ctx *ctx = g->ctx;
   if (ctx->capturing) return fail(MGX_ESTATE, "mgx_graph_launch: the context is recording");
   if (ctx->levels != g->levels) return fail(MGX_ESTATE, "mgx_graph_launch: the context's levels are not those of the recording");
+  // the recorded kernels carry the box tables, tile lists and parameters of the recording: a level that was given new
+  // ones since (or a new level at an old address) must be recorded again
+  for (size_t i = 0; i < g->levels.size(); ++i)
+    if (g->levels[i]->uid != g->uid[i] || g->levels[i]->epoch != g->epoch[i])
+      return fail(MGX_ESTATE, "mgx_graph_launch: level %d was given new parameters, boxes or tile lists after the graph "
+                  "was recorded: record it again", g->levels[i]->layer);
   for (size_t i = 0; i < g->levels.size(); ++i)
     if (!same_state(level_state(g->levels[i]), g->from[i]))
       return fail(MGX_ESTATE, "mgx_graph_launch: level %d is not in the state the graph was recorded from", g->levels[i]->layer);
@@ -399,6 +411,7 @@ extern "C" int mgx_level_create_slab(mgx_ctx *ctx, int layer, const int32_t n[3]
   mgx_level *lv = new mgx_level();
   lv->ctx = ctx;
   lv->layer = layer;
+  lv->uid = ++g_level_uid;
   lv->elem = elem_bytes;
   const int align = 128 / elem_bytes;      // elements per 128 bytes
   MgxGeom &g = lv->g;
@@ -488,6 +501,7 @@ extern "C" int mgx_level_set_params(mgx_level *lv, double sor, const double a[3]
   for (int i = 0; i < 3; ++i) lv->a[i] = a[i];
   for (int i = 0; i < 6; ++i) lv->bc[i] = bc[i];
   lv->params_set = true;
+  ++lv->epoch;
   return MGX_OK;
 }
 
@@ -528,6 +542,7 @@ extern "C" int mgx_level_set_boxes(mgx_level *lv, int32_t nbox, const int32_t *p
   lv->count_cache = -1;
   lv->plan.valid = false;
   lv->plan2.valid = false;
+  ++lv->epoch;
   return MGX_OK;
 }
 
@@ -620,6 +635,12 @@ extern "C" int mgx_level_result_reset(mgx_level *lv) {
   if (!lv) return fail(MGX_EINVAL, "mgx_level_result_reset: NULL level");
   TRY(set_device(C(lv)));
   return reset_result(lv);
+}
+
+// (re)build a tile list of the level; the old list is freed, so graphs recorded with it are void
+static int make_plan(mgx_level *lv, MgxFusedPlan &pl, int ns) {
+  ++lv->epoch;
+  return mgx_fused_make_plan(pl, lv->g, lv->boxes, C(lv)->stream, ns);
 }
 
 template <typename T>
@@ -716,7 +737,7 @@ static int do_sweeps(mgx_level *lv, int nsweeps, int reduce) {
       if (red) TRY(prepare_single_pass(lv));
       TRY(sync_shell<T>(lv));
       if (!lv->plan2.valid) NOT_WHILE_CAPTURING(C(lv), "mgx_level_sweep (first pair pass of a level builds its tile lists)");
-      if (!lv->plan2.valid && mgx_fused_make_plan(lv->plan2, g, lv->boxes, C(lv)->stream, 2) != 0)
+      if (!lv->plan2.valid && make_plan(lv, lv->plan2, 2) != 0)
         return fail(MGX_EHIP, "mgx_level_sweep: could not build the tile lists of the two-sweep kernel");
       if (mgx_tb2_launch(lv->plan2, (const T *)lv->buf[lv->cur], (T *)lv->buf[1 - lv->cur], g,
                                                     make_params<T>(lv), lv->d_boxes, lv->nbox, red, lv->d_res,
@@ -732,7 +753,7 @@ static int do_sweeps(mgx_level *lv, int nsweeps, int reduce) {
     if (which == MGX_KERNEL_FUSED) {
       TRY(sync_shell<T>(lv));
       if (!lv->plan.valid) NOT_WHILE_CAPTURING(C(lv), "mgx_level_sweep (first sweep of a level builds its tile lists)");
-      if (!lv->plan.valid && mgx_fused_make_plan(lv->plan, g, lv->boxes, C(lv)->stream) != 0)
+      if (!lv->plan.valid && make_plan(lv, lv->plan, 1) != 0)
         return fail(MGX_EHIP, "mgx_level_sweep: could not build the tile lists of the fused kernel");
       if (mgx_fused_launch(lv->plan, 0, (const T *)lv->buf[lv->cur], (T *)lv->buf[1 - lv->cur], g, make_params<T>(lv),
                               lv->d_boxes, lv->nbox, red, lv->d_res, C(lv)->stream) != 0)
@@ -782,7 +803,7 @@ static int do_sweep_part(mgx_level *lv, int part, int reduce) {
     if (reduce) TRY(prepare_single_pass(lv));
     TRY(sync_shell<T>(lv));
     if (!lv->plan.valid) NOT_WHILE_CAPTURING(C(lv), "mgx_level_sweep_part (first sweep of a level builds its tile lists)");
-    if (!lv->plan.valid && mgx_fused_make_plan(lv->plan, g, lv->boxes, C(lv)->stream) != 0)
+    if (!lv->plan.valid && make_plan(lv, lv->plan, 1) != 0)
       return fail(MGX_EHIP, "mgx_level_sweep_part: could not build the tile lists of the fused kernel");
     if (mgx_fused_launch(lv->plan, 1, (const T *)lv->buf[lv->cur], (T *)lv->buf[1 - lv->cur], g, make_params<T>(lv),
                             lv->d_boxes, lv->nbox, reduce, lv->d_res, C(lv)->stream) != 0)
@@ -841,7 +862,7 @@ static int do_solve(mgx_level *lv, double tol_level, double nr, double old_sum, 
   if (!c->h_solve) HIP_TRY(hipHostMalloc((void **)&c->h_solve, sizeof(MgxSolveState) + sizeof(double) * 3 * MGX_SOLVE_BATCH, hipHostMallocDefault));
   double *d_hist = reinterpret_cast<double *>(lv->d_solve + 1);
   TRY(sync_shell<T>(lv));
-  if (!lv->plan.valid && mgx_fused_make_plan(lv->plan, g, lv->boxes, st) != 0)
+  if (!lv->plan.valid && make_plan(lv, lv->plan, 1) != 0)
     return fail(MGX_EHIP, "mgx_level_solve: could not build the tile lists of the fused kernel");
   MgxSolveState init;
   init.stop = 0; init.count = 0; init.old_sum = (double)(T)old_sum;

@@ -7,6 +7,8 @@
 
 typedef unsigned long long u64;
 
+#define MGX_MAX_DEVICES 64   /* per-device tables of the library (static scratch address, kernel attributes) */
+
 // One box of the level's table (t_mg.f90:62-72).  val and rho are stored already rounded to the
 // level's precision, widened to double.
 struct MgxBox {

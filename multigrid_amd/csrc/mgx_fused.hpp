@@ -690,14 +690,14 @@ static int mgx_fused_launch_cfg(const MgxFusedPlan &pl, int part, const T *src, 
   constexpr int TXP = 64;
   constexpr size_t lds = (size_t)3 * 2 * (TXP + 2) * (TY + 6) * sizeof(T) + sizeof(MgxBoxLds<T>);
   if (lds > 64 * 1024) {        // beyond the default dynamic LDS limit: raise it once per device and function
-    static bool attr_done[16] = {false};
+    static bool attr_done[MGX_MAX_DEVICES] = {false};
     int dev = 0;
     if (hipGetDevice(&dev) != hipSuccess) return -1;
-    if (!(dev >= 0 && dev < 16 && attr_done[dev])) {
+    if (!(dev >= 0 && dev < MGX_MAX_DEVICES && attr_done[dev])) {
       if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_fused_sweep<T, TY, NW>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
         return -1;
-      if (dev >= 0 && dev < 16) attr_done[dev] = true;
+      if (dev >= 0 && dev < MGX_MAX_DEVICES) attr_done[dev] = true;
     }
   }
   const MgxTileList &tl = pl.list[part];

@@ -458,14 +458,14 @@ template <typename T, int NS, int TY, int NW, int DF>
 static int mgx_tb_launch_cfg(const MgxFusedPlan &pl, const T *src, T *dst, const MgxGeom &g, const MgxSweepParams<T> &p,
                              const MgxBox *bx, int nb, int reduce, u64 *res, hipStream_t st) {
   constexpr size_t lds = mgx_tb_lds_field<T, NS, TY, NW>() + sizeof(MgxBoxLds<T>);
-  static bool attr_done[16] = {false};          // the attribute is per device and function: set once per device
+  static bool attr_done[MGX_MAX_DEVICES] = {false};          // the attribute is per device and function: set once per device
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess) return -1;
-  if (lds > 64 * 1024 && !(dev >= 0 && dev < 16 && attr_done[dev])) {
+  if (lds > 64 * 1024 && !(dev >= 0 && dev < MGX_MAX_DEVICES && attr_done[dev])) {
     if (hipFuncSetAttribute(reinterpret_cast<const void *>(k_tb_sweep<T, NS, TY, NW, DF>),
                             hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds) != hipSuccess)
       return -1;
-    if (dev >= 0 && dev < 16) attr_done[dev] = true;
+    if (dev >= 0 && dev < MGX_MAX_DEVICES) attr_done[dev] = true;
   }
   const MgxTileList &tl = pl.list[0];
   const int total = tl.n_box + tl.n_const + tl.n_fast;

@@ -36,12 +36,22 @@ def divergence_hint(sor: float) -> str:
             f"mgx_ctx_set_kernel(ctx, MGX_KERNEL_LEX): slower, the reference's results bit for bit).")
 
 
+ORDER_AUTO, ORDER_RED_BLACK, ORDER_REFERENCE = "auto", "red-black", "reference"
+
+
 class Solver:
     """Owns the device context and the resident levels of one hierarchy."""
 
     def __init__(self, top: G.MgGrid, device: int = 0, stream: Optional[int] = None, ctx: Optional[lib.Context] = None,
                  verbose: bool = False, print_sums: bool = True, max_sweeps: int = 1 << 24, device_loop: bool = True,
-                 use_graphs: bool = False):
+                 use_graphs: bool = False, order: str = ORDER_AUTO):
+        if order not in (ORDER_AUTO, ORDER_RED_BLACK, ORDER_REFERENCE):
+            raise ValueError(f"order = {order!r}")
+        # sweep order: "red-black" (the fast kernels), "reference" (gs's own order, m_gs_CDS.F90:317-345: the
+        # reference's results bit for bit at any over-relaxation, slower), "auto" = red-black unless a V cycle is asked
+        # for with an over-relaxation beyond what that ordering takes (the parser's default 1.8 among them,
+        # m_mg_io.F90:87): every input the reference solves must solve here
+        self.order = order
         self.top = top
         self.ctx = ctx if ctx is not None else lib.Context(device, stream)
         self.own_ctx = ctx is None
@@ -154,9 +164,33 @@ class Solver:
         return np.array(self.history, dtype=HIST_DTYPE)
 
     # -- m_gs_CDS -----------------------------------------------------------------------------------
+    reference_order_available = True       # (a decomposed solver has no kernel for the reference's order)
+
+    def choose_order(self, method: int):
+        """select the sweep kernel for a solve by `method` (see `order` in __init__)"""
+        if self.order == ORDER_RED_BLACK:
+            return
+        want = self.order == ORDER_REFERENCE
+        if not want and method == CDS_W_CYCLE:
+            high = [float(g.sor) for g in self.top.levels() if g.enabled and float(g.sor) > RB_SOR_LIMIT]
+            if high:
+                want = self.reference_order_available
+                import sys
+                if want:
+                    print(f"multigrid_amd: `method v-cycle` with sor = {max(high):g} > {RB_SOR_LIMIT:g}: sweeping in the "
+                          "reference's own order (its results bit for bit; the red-black kernels are stable up to "
+                          f"sor {RB_SOR_LIMIT:g} and several times faster)", file=sys.stderr)
+                else:
+                    print("warning: `method v-cycle` with sor > 1.7." + divergence_hint(max(high)), file=sys.stderr)
+        if want:
+            if not self.reference_order_available:
+                raise G.MgStop("the reference's sweep order needs undivided levels")
+            self.ctx.set_kernel(lib.KERNEL_LEX)
+
     def mg_gs_cds(self, method: int = CDS_BOTTOM_UP, init: Optional[bool] = None):
         """m_gs_CDS.F90:21-57"""
         top = self.top
+        self.choose_order(method)
         if init is None or init:
             self.bring_back(top)
             self.setup(top, True)
@@ -213,30 +247,37 @@ class Solver:
         if solve is None:
             return False
         t = self.t
-        budget = self.max_sweeps - self.total_sweeps
-        if budget <= 0:
-            raise G.MgStop(f"more than {self.max_sweeps} sweeps")
-        try:
-            hist, n, status = solve(float(gtol), self.count(grid), float(old_sum), budget)
-        except lib.MgxError as e:
-            if e.code == -4:              # MGX_ESTATE: not on this level
-                return False
-            raise
-        for tol_, sum_, e2 in hist:
-            grid.itt += 1
-            self.total_sweeps += 1
-            grid.err = float(np.sqrt(t(e2)))
-            grid.err_pending = False
-            if sum_ != sum_:
-                break
-            self.record(grid, 0, t(tol_), t(sum_))
-            self.say(f" itt {grid.itt - old_itt:6d} {float(t(tol_)):10.7f} {float(t(sum_) * nr):10.7f} {grid.err:10.7f}")
-        if status == 2:
-            raise G.MgStop(f"layer {grid.layer}: |V| reached 2^20 or is not finite after {grid.itt} sweeps: the iteration diverges."
-                           + divergence_hint(float(grid.sor)))
-        if status == 1:
-            raise G.MgStop(f"more than {self.max_sweeps} sweeps")
-        return True
+        # one call takes at most SOLVE_CHUNK sweeps (its history array is sized for them); a level that needs more is
+        # continued from the state the call left (old_sum = the last sum), like the loop of grid_solve itself, which
+        # has no cap (m_gs_CDS.F90:200)
+        while True:
+            budget = self.max_sweeps - self.total_sweeps
+            if budget <= 0:
+                raise G.MgStop(f"more than {self.max_sweeps} sweeps")
+            try:
+                hist, n, status = solve(float(gtol), self.count(grid), float(old_sum), min(budget, self.SOLVE_CHUNK))
+            except lib.MgxError as e:
+                if e.code == -4:              # MGX_ESTATE: not on this level
+                    return False
+                raise
+            assert n == len(hist)
+            for tol_, sum_, e2 in hist:
+                grid.itt += 1
+                self.total_sweeps += 1
+                grid.err = float(np.sqrt(t(e2)))
+                grid.err_pending = False
+                if sum_ != sum_:
+                    break
+                self.record(grid, 0, t(tol_), t(sum_))
+                old_sum = t(sum_)
+                self.say(f" itt {grid.itt - old_itt:6d} {float(t(tol_)):10.7f} {float(t(sum_) * nr):10.7f} {grid.err:10.7f}")
+            if status == 2:
+                raise G.MgStop(f"layer {grid.layer}: |V| reached 2^20 or is not finite after {grid.itt} sweeps: the iteration diverges."
+                               + divergence_hint(float(grid.sor)))
+            if status == 0:
+                return True
+
+    SOLVE_CHUNK = 1 << 16
 
     def _leg(self, grid, want_sum: bool = False, defer: bool = False):
         """steps × gs_step between two (print-only) sums: m_gs_CDS.F90:237-248 / :268-278.  Returns the grid_sum

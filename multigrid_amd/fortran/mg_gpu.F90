@@ -8,7 +8,7 @@
 ! `noprint` leaves out the sums gs_V evaluates only to print them (m_gs_CDS.F90:238,245,269,275).  The wall time
 ! of the solve (hierarchy resident, first kernel to last result) is printed on the last line.
 !
-! case.txt (list-directed):  nlevels method kernel
+! case.txt (list-directed):  nlevels method kernel     (kernel = MGX_KERNEL_*; 0 lets the host choose the sweep order)
 !   per level:  n1 n2 n3 / sor / a1 a2 a3 / tol / steps / A0 A1 B0 B1 C0 C1 / restrict prolong / enabled / nbox
 !               per box: xmin xmax ymin ymax zmin zmax val rho constant(0|1)
 ! out.bin (stream): nrec, layer(nrec), kind(nrec), itt(nrec) [int32]; tol, sum, err (nrec) [real64];
@@ -70,6 +70,7 @@ program mg_gpu
 
   call mgx_check(mgx_ctx_create(0_c_int, c_null_ptr, ctx))
   call mgx_check(mgx_ctx_set_kernel(ctx, int(kernel, c_int)))
+  if ( kernel /= 0 ) sweep_order = ORDER_KEEP      ! the case file names a kernel: no automatic choice of the order
   call host_attach(ctx, lv(1))
   call mgx_check(mgx_ctx_sync(ctx))
   call system_clock(t0, rate)

@@ -56,6 +56,13 @@ module mgx_host
   logical, public, save :: print_sums = .true.     ! evaluate the print-only sums of gs_V (m_gs_CDS.F90:238,245,269,275)
   logical, public, save :: verbose = .false.
   logical, public, save :: device_loop = .true.     ! grid_solve's convergence loop through mgx_level_solve where it applies
+  ! Sweep order of a solve.  ORDER_AUTO: the red-black kernels, unless a V cycle is asked for with an over-relaxation
+  ! that ordering does not take (sor > RB_SOR_LIMIT; the reference parser's default 1.8, m_mg_io.F90:87, among them):
+  ! then gs's own order (m_gs_CDS.F90:317-345; MGX_KERNEL_LEX: the reference's results bit for bit, slower), with one
+  ! line on the error unit.  ORDER_KEEP leaves the context's kernel selection alone.
+  integer, parameter, public :: ORDER_AUTO = 0, ORDER_KEEP = 1, ORDER_REFERENCE = 2
+  integer, public, save :: sweep_order = ORDER_AUTO
+  real(grid_p), parameter, public :: RB_SOR_LIMIT = 1.7_grid_p
 
   public :: host_attach, host_detach
   public :: mg_gs_cds, gs_bottom_up, gs_w, gs_V, grid_solve
@@ -241,6 +248,7 @@ contains
     logical :: linit
     lmethod = CDS_BOTTOM_UP
     if ( present(method) ) lmethod = method
+    call choose_order(top, lmethod)
     linit = .true.
     if ( present(init) ) linit = init
     if ( linit ) then
@@ -256,6 +264,35 @@ contains
        stop 'Error on method used for CDS'
     end select
   end subroutine mg_gs_cds
+
+  subroutine choose_order(top, method)
+    use, intrinsic :: iso_fortran_env, only: error_unit
+    type(host_grid), intent(in), target :: top
+    integer, intent(in) :: method
+    type(host_grid), pointer :: g
+    type(c_ptr) :: ctx
+    real(grid_p) :: high
+    logical :: want
+    if ( sweep_order == ORDER_KEEP ) return
+    want = sweep_order == ORDER_REFERENCE
+    if ( .not. want .and. method == CDS_W_CYCLE ) then
+       high = 0._grid_p
+       g => top
+       do while ( associated(g) )
+          if ( g%enabled ) high = max(high, g%sor)
+          g => g%child
+       end do
+       if ( high > RB_SOR_LIMIT ) then
+          want = .true.
+          write(error_unit,'(a,f6.3,a)') 'mgx_host: v-cycle with sor =', high, &
+               ' > 1.7: sweeping in the reference''s own order (red-black is stable up to 1.7 and faster)'
+       end if
+    end if
+    if ( want ) then
+       call mgx_check(mgx_level_context(top%h, ctx))
+       call mgx_check(mgx_ctx_set_kernel(ctx, MGX_KERNEL_LEX))
+    end if
+  end subroutine choose_order
 
   subroutine gs_bottom_up(top)                      ! m_gs_CDS.F90:59-104
     type(host_grid), intent(inout), target :: top
@@ -309,31 +346,38 @@ contains
     type(host_grid), intent(inout) :: grid
     real(grid_p), intent(in) :: nr, gtol, old_sum
     logical :: done
-    integer(c_int64_t), parameter :: cap = 1048576_c_int64_t
+    integer(c_int64_t), parameter :: cap = 65536_c_int64_t      ! sweeps per call (and rows of the history array)
     real(c_double), allocatable :: hist(:,:)
     integer(c_int64_t) :: n, i
     integer(c_int32_t) :: status
     integer(c_int) :: rc
-    real(grid_p) :: tol, new_sum
+    real(grid_p) :: tol, new_sum, cur_sum
     allocate(hist(3, cap))
-    rc = mgx_level_solve(grid%h, real(gtol, c_double), int(grid_non_constant_elem(grid), c_int64_t), real(old_sum, c_double), &
-         cap, cap, hist, n, status)
-    if ( rc == MGX_ESTATE ) then
-       done = .false.
-       return
-    end if
-    call mgx_check(rc)
-    do i = 1, n
-       grid%itt = grid%itt + 1
-       tol = real(hist(1, i), grid_p)
-       new_sum = real(hist(2, i), grid_p)
-       grid%err = sqrt(real(hist(3, i), grid_p))
-       grid%err_pending = .false.
-       call record(grid, 0, tol, new_sum)
-       if ( verbose ) write(*,'(a,i6,3(tr1,f10.7))') ' itt ', grid%itt, tol, new_sum * nr, grid%err
+    cur_sum = old_sum
+    ! a level that needs more than `cap` sweeps is continued from the state the call left: the reference's loop
+    ! has no cap (m_gs_CDS.F90:200)
+    do
+       rc = mgx_level_solve(grid%h, real(gtol, c_double), int(grid_non_constant_elem(grid), c_int64_t), real(cur_sum, c_double), &
+            cap, cap, hist, n, status)
+       if ( rc == MGX_ESTATE ) then
+          done = .false.
+          return
+       end if
+       call mgx_check(rc)
+       do i = 1, n
+          grid%itt = grid%itt + 1
+          tol = real(hist(1, i), grid_p)
+          new_sum = real(hist(2, i), grid_p)
+          grid%err = sqrt(real(hist(3, i), grid_p))
+          grid%err_pending = .false.
+          if ( new_sum /= new_sum ) exit
+          call record(grid, 0, tol, new_sum)
+          cur_sum = new_sum
+          if ( verbose ) write(*,'(a,i6,3(tr1,f10.7))') ' itt ', grid%itt, tol, new_sum * nr, grid%err
+       end do
+       if ( status == 2 ) stop 'mgx_host: |V| reached 2^20 or is not finite: the iteration diverges'
+       if ( status == 0 ) exit
     end do
-    if ( status == 2 ) stop 'mgx_host: |V| reached 2^20 or is not finite: the iteration diverges'
-    if ( status == 1 ) stop 'mgx_host: grid_solve did not meet its tolerance within 1048576 sweeps'
     done = .true.
   end function solve_on_device
 

@@ -287,7 +287,7 @@ class DeviceLevel:
     def solve(self, tol_level: float, count: int, old_sum: float, max_sweeps: int):
         """grid_solve's loop with the convergence test on the device: (history array [n][3] of tol, sum, max dV^2;
         status 0 converged / 1 max_sweeps / 2 sum out of range)"""
-        cap = int(max(1, min(max_sweeps, 1 << 20)))
+        cap = int(max(1, max_sweeps))       # every sweep gets its row (callers ask for chunks of sweeps)
         hist = np.zeros((cap, 3), dtype=np.float64)
         n, st = C.c_int64(), C.c_int32()
         _ck(self.L.mgx_level_solve(self.h, float(tol_level), int(count), float(old_sum), int(max_sweeps), cap,

@@ -428,6 +428,7 @@ class SlabSolver:
 
         class _Solver(cycle.Solver):
             edge = None                          # the slab of the first replicated level's geometry
+            reference_order_available = world == 1 and level_factory is None   # a slab has no kernel for that order
 
             def make_level(self, g):
                 if g.layer in rep_layers:

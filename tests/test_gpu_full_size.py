@@ -204,3 +204,51 @@ def test_full_extent_slabs_2048x2048x256(ctx):
         ctx.set_kernel(0)
         for lv in made:
             lv.close()
+
+
+def _random_state(L, seed):
+    """a field of noise (every cell non-zero: a wrong neighbour, weight or plane shows in the bits), boxes imprinted and
+    ghost faces filled as grid_setup leaves them"""
+    rng = np.random.default_rng(seed)
+    V = rng.standard_normal(L.shape()).astype(np.float64)
+    orc.setup(L, V, False)
+    return V
+
+
+def _pair_passes_against_oracle(ctx, g, L, seed):
+    """`mgx_level_sweep(lv, 2)` and `(lv, 4)` under the automatic kernel selection (the two-sweeps-per-pass kernel with
+    the tile lists the library builds for this size) against as many oracle sweeps: field, max dV^2, exact sum"""
+    from multigrid_amd import lib
+    V = _random_state(L, seed)
+    lv = _device(ctx, g)
+    try:
+        lv.upload(V)
+        red = lib.RED_ERR | lib.RED_SUM
+        for nsw in (2, 4):
+            for _ in range(nsw):
+                e2 = orc.sweep(L, V, orc.ORDER_RB)
+            s, units = orc.abs_sum_exact(L, V)
+            lv.sweep(nsw, red)
+            assert lv.result() == (e2, s, units), nsw
+            assert bits_equal(lv.download(), V), nsw
+    finally:
+        lv.close()
+
+
+def test_pair_pass_as_selected_at_512_matches_oracle(ctx, hierarchy):
+    """the kernel behind gs_V's legs (m_gs_CDS.F90:240-242, 271-273) at the size and with the tile lists (whole chunks,
+    halves, quarters, pieces that boxes reach) the V-cycle benchmark runs it with"""
+    top = hierarchy
+    ctx.set_kernel(0)
+    _pair_passes_against_oracle(ctx, top, oracle_levels(top)[0], 512)
+
+
+def test_pair_pass_cut_tail_2048x2048x64_matches_oracle(ctx):
+    """one chunk of 64 planes per tile column, 1504 columns: the lists with halves and quarters of chunks on a level
+    of one chunk; rows of 2048 cells (16 tile columns)"""
+    from bench import config5_input
+    from multigrid_amd import mgio
+    top = mgio.iomg_read(mgio.MgIO(text=config5_input((2048, 2048, 64))), dtype=np.float64)
+    assert [int(v) for v in top.n] == [2048, 2048, 64]
+    ctx.set_kernel(0)
+    _pair_passes_against_oracle(ctx, top, oracle_levels(top)[0], 2048)

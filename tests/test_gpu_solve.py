@@ -62,7 +62,7 @@ def test_divergent_solve_is_reported():
     method = mgio.read_method(IO)
     _, hist, _ = orc.solve(oracle_levels(top), method, np.float64, order=orc.ORDER_RB, sum_mode=orc.SUM_EXACT)
     assert np.isnan(hist["sum"]).any()
-    s = cycle.Solver(top)
+    s = cycle.Solver(top, order=cycle.ORDER_RED_BLACK)
     try:
         from multigrid_amd import grid as G
         with pytest.raises((lib.MgxError, G.MgStop)) as e:
@@ -72,15 +72,41 @@ def test_divergent_solve_is_reported():
         s.close()
 
 
-def test_mg_program_warns_at_the_parsers_default_sor(tmp_path, capsys):
-    """an input without a `sor` line gets the parser's default 1.8 (m_mg_io.F90:87): `python -m multigrid_amd` says up
-    front that the red-black v-cycle is not stable there, and stops with the same advice instead of iterating on"""
-    from multigrid_amd import __main__ as prog
-    text = str(load("solve_80_v_f64")["input"])
+def _default_sor_input(tmp_path):
+    """solve_80_v without its `sor` line: the parser's default 1.8 applies (m_mg_io.F90:87), which is also what the
+    golden run of the reference used"""
+    g = load("solve_80_v_f64")
+    text = str(g["input"])
+    assert "sor 1.8" in text
     lines = [l for l in text.splitlines() if not l.strip().startswith("sor")]
+    lines = [(f"save {tmp_path / 'out.vmg'}" if l.strip().startswith("save") else l) for l in lines]
+    if not any(l.strip().startswith("save") for l in lines):
+        lines.insert(0, f"save {tmp_path / 'out.vmg'}")
     f = tmp_path / "mg.input"
     f.write_text("\n".join(lines) + "\n")
+    return f, g
+
+
+def test_mg_program_solves_the_parsers_default_sor_like_the_reference(tmp_path, capsys):
+    """`python -m multigrid_amd` without any flag on a v-cycle input at the parser's default over-relaxation: the
+    program selects the reference's sweep order by itself (one line on stderr) and writes the field the reference's
+    own `mg` program wrote for this input, bit for bit"""
+    from multigrid_amd import __main__ as prog
+    f, g = _default_sor_input(tmp_path)
     rc = prog.main(["--double", str(f)])
+    err = capsys.readouterr().err
+    assert rc == 0
+    assert "reference's own order" in err and len(err.strip().splitlines()) == 1
+    *_, V = mgio.read_vmg(mgio.vmg_name(str(tmp_path / "out.vmg")), dtype=np.float64)
+    assert bits_equal(np.ascontiguousarray(V), np.ascontiguousarray(g["V"]))
+
+
+def test_mg_program_red_black_flag_warns_and_reports_divergence(tmp_path, capsys):
+    """`--red-black` keeps the fast kernels: the program says up front that the ordering is not stable at this
+    over-relaxation and stops with the same advice instead of iterating on"""
+    from multigrid_amd import __main__ as prog
+    f, _ = _default_sor_input(tmp_path)
+    rc = prog.main(["--double", "--red-black", str(f)])
     err = capsys.readouterr().err
     assert rc == 1
     assert "warning" in err and "sor 1.7" in err and "diverges" in err
@@ -208,3 +234,60 @@ def test_reference_order_test6_fp64():
         assert bits_equal(np.ascontiguousarray(W[1:-1][::sub, ::sub, ::sub]), np.ascontiguousarray(g["V"]))
     finally:
         s.close()
+
+
+def test_recorded_graph_is_void_after_new_boxes_or_parameters():
+    """a recorded graph carries the box table, tile lists and sweep parameters of the recording in its kernel
+    arguments: mgx_graph_launch must refuse (MGX_ESTATE) once mgx_level_set_boxes / mgx_level_set_params have replaced
+    them, and a new recording must work and see the new table"""
+    from multigrid_amd import lib
+    n = (40, 24, 16)
+    L = orc.Level(n=n, bc=(1, 1, 2, 3, 2, 2), sor=1.5, a=(1 / 3,) * 3,
+                  boxes=[orc.Box((5, 20, 3, 9, 2, 6), 0.5, 1.0, True)])
+    L2 = orc.Level(n=n, bc=(1, 1, 2, 3, 2, 2), sor=1.5, a=(1 / 3,) * 3,
+                   boxes=[orc.Box((8, 30, 10, 20, 8, 12), -0.25, 1.0, True), orc.Box((2, 6, 2, 6, 2, 6), 0.0, 3.0, False)])
+    rng = np.random.default_rng(5)
+    V0 = rng.standard_normal(L.shape())
+    ctx = lib.Context(0)
+    try:
+        lv = ctx.level(1, n, np.float64)
+
+        def give(Lx):
+            lv.set_params(Lx.sor, Lx.a, Lx.bc)
+            lv.set_boxes([b.place for b in Lx.boxes], [b.val for b in Lx.boxes], [b.rho for b in Lx.boxes],
+                         [int(b.constant) for b in Lx.boxes])
+
+        def record():
+            ctx.capture_begin()
+            lv.sweep(2, 0)
+            return ctx.capture_end()
+
+        give(L)
+        V = V0.copy()
+        orc.setup(L, V, False)
+        lv.upload(V)
+        lv.sweep(2, 0)                      # tile lists exist from here on
+        gr = record()
+        gr.launch()
+        for _ in range(4):
+            orc.sweep(L, V, orc.ORDER_RB)
+        assert bits_equal(lv.download(), V)
+        give(L2)                            # frees the box table and the tile lists the graph points at
+        with pytest.raises(lib.MgxError) as e:
+            gr.launch()
+        assert e.value.code == -4 and "record it again" in str(e.value)
+        V = V0.copy()
+        orc.setup(L2, V, False)
+        lv.upload(V)
+        lv.sweep(2, 0)
+        gr2 = record()
+        gr2.launch()
+        for _ in range(4):
+            orc.sweep(L2, V, orc.ORDER_RB)
+        assert bits_equal(lv.download(), V)
+        lv.set_params(1.2, L2.a, L2.bc)     # sor is a kernel argument of the recording
+        with pytest.raises(lib.MgxError) as e:
+            gr2.launch()
+        assert e.value.code == -4
+    finally:
+        ctx.close()
