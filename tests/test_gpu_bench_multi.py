@@ -34,8 +34,8 @@ def _run_bench(extra):
     return json.loads(lines[0])
 
 
-@pytest.mark.parametrize("extra", [["--dist-size", "64"], ["--config", "4", "--dist-size", "32"]],
-                         ids=["config5_64", "config4_32x32x512"])
+@pytest.mark.parametrize("extra", [["--dist-size", "64"], ["--config", "4", "--dist-size", "48"]],
+                         ids=["config5_64", "config4_48x48x768"])
 def test_two_rank_bench_line(extra):
     out = _run_bench(extra)
     assert out["n_gpus"] == 2 and out["steps"] == 2 and out["warmup"] == 1
