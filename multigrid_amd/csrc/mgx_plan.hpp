@@ -12,7 +12,7 @@
 // tile height and row waves of the two-sweeps-per-pass kernel (the tile lists and the kernel must agree)
 #ifndef MGX_TB_TY
 #define MGX_TB_TY 22
-#define MGX_TB_NW 6
+#define MGX_TB_NW 15
 #endif
 
 struct MgxTileList {             // segment sizes, each padded to a multiple of 8, and where the list starts
@@ -59,7 +59,7 @@ static int mgx_fused_make_plan(MgxFusedPlan &pl, const MgxGeom &g, const std::ve
       pl.ty = mgx_fused_ty; pl.nw = mgx_fused_nw;
     }
   }
-  if (ns == 2) { pl.ty = MGX_TB_TY; pl.nw = MGX_TB_NW; }   // the temporally blocked kernel: 128 x 22 tiles on 6 row waves
+  if (ns == 2) { pl.ty = MGX_TB_TY; pl.nw = MGX_TB_NW; }   // the temporally blocked kernel: 128 x 22 tiles, 15 row waves of two rows
   pl.ntx = (g.n1 + 2 * TXP - 1) / (2 * TXP);
   pl.nty = (g.n2 + pl.ty - 1) / pl.ty;
   // z chunk: at least three rounds of blocks on 256 compute units (tiles differ in cost: the rounds even that

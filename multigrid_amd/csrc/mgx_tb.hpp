@@ -31,6 +31,19 @@
 
 #include "mgx_fused.hpp"
 
+// waves of a block: NW row waves, the wave of the x-halo pairs, and (MGX_TB_PREFETCH) one that only touches the
+// planes ahead (mgx_tb_prefetch_wave)
+#ifndef MGX_TB_PREFETCH
+#define MGX_TB_PREFETCH 0
+#endif
+#ifndef MGX_TB_PREFETCH_AHEAD
+#define MGX_TB_PREFETCH_AHEAD 2                  /* planes ahead of the plane the working waves load in the same step */
+#endif
+#define MGX_TB_WAVES(NW) ((NW) + 1 + (MGX_TB_PREFETCH ? 1 : 0))
+#ifndef MGX_TB_EDGE_STRIPS
+#define MGX_TB_EDGE_STRIPS 1                     /* the first and the last strip of rows leave out the rows a stage does not need */
+#endif
+
 // The step barrier orders LDS traffic only: wait for this wave's LDS operations, not for its global loads and
 // stores (which __syncthreads() would drain: the planes in flight and the plane just stored).
 #ifndef MGX_TB_SYNC
@@ -55,12 +68,60 @@ __device__ __forceinline__ double mgx_abs_if(const double v, const bool cond) {
 // FREE: row wave of a box-free tile whose staged rows and 128 columns are all interior (see mgx_fused_body): every
 // stage updates every cell of the wave unconditionally; what that computes outside the stage's region is read only
 // by cells outside the next stage's region, never stored and never counted.
-template <typename T, int NS, int TY, int BOXES, int NW, int DF, int P0, bool HALO, bool FREE = false>
-__device__ __forceinline__ void mgx_tb_body(const T *__restrict__ src, T *__restrict__ dst, const MgxGeom &g,
-                                            const MgxSweepParams<T> &p, const MgxBox *__restrict__ bx, const int nb,
-                                            const int tx0, const int ty0, const int zc0, const int zc1,
-                                            const int reduce, u64 *__restrict__ res, T *__restrict__ lds,
-                                            MgxBoxLds<T> *__restrict__ bl, const int n_commit) {
+// wave-uniform values that reach a function as arguments arrive in vector registers: back into scalar ones
+// (MGX_TB_UNI: only where the bodies are functions of their own; inlined into the kernel they see the kernel's
+// arguments, which the compiler can load again from the argument segment instead of keeping them in registers)
+#ifndef MGX_TB_NOINLINE
+#define MGX_TB_NOINLINE 0
+#endif
+#if MGX_TB_NOINLINE
+#define MGX_TB_UNI(x) mgx_uni(x)
+#else
+#define MGX_TB_UNI(x) (x)
+#endif
+__device__ __forceinline__ int mgx_uni(const int v) { return __builtin_amdgcn_readfirstlane(v); }
+__device__ __forceinline__ long long mgx_uni(const long long v) {
+  const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(v & 0xffffffffll));
+  const unsigned hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)((unsigned long long)v >> 32));
+  return (long long)(((unsigned long long)hi << 32) | lo);
+}
+__device__ __forceinline__ double mgx_uni(const double v) { return __longlong_as_double(mgx_uni(__double_as_longlong(v))); }
+__device__ __forceinline__ float mgx_uni(const float v) { return __int_as_float(__builtin_amdgcn_readfirstlane(__float_as_int(v))); }
+template <typename P> __device__ __forceinline__ P *mgx_uni(P *const v) { return reinterpret_cast<P *>(mgx_uni((long long)v)); }
+
+// One instantiation per (box class, parity, kind of wave): a function of its own (not inlined into the kernel), so
+// that each variant gets a register allocation of its own; the block-uniform arguments are made scalar again first.
+#ifndef MGX_TB_NOINLINE
+#define MGX_TB_NOINLINE 0
+#endif
+#if MGX_TB_NOINLINE
+#define MGX_TB_BODY_ATTR __attribute__((noinline))
+#else
+#define MGX_TB_BODY_ATTR __forceinline__
+#endif
+// EDGE: which strip of rows a row wave owns: 1 the lowest rows of the staged region, 2 the highest, 0 one in between.
+// Half-sweep s works on the staged rows s + 1 .. LR - 2 - s, so the first and the last strip hold rows that only the
+// early half-sweeps need: those waves leave out the rows a stage does not need, at compile time.
+template <typename T, int NS, int TY, int BOXES, int NW, int DF, int P0, bool HALO, bool FREE = false, int EDGE = 0>
+__device__ MGX_TB_BODY_ATTR void mgx_tb_body(const T *__restrict__ src_, T *__restrict__ dst_, const MgxGeom g_,
+                                            const MgxSweepParams<T> p_, const MgxBox *__restrict__ bx_, const int nb_,
+                                            const int tx0_, const int ty0_, const int zc0_, const int zc1_,
+                                            const int reduce_, u64 *__restrict__ res_, T *__restrict__ lds,
+                                            MgxBoxLds<T> *__restrict__ bl, const int n_commit_, const int strip_) {
+  const int strip = MGX_TB_UNI(strip_);             // the strip of rows of a row wave (see mgx_tb_tile)
+  const T *__restrict__ src = MGX_TB_UNI(src_);
+  T *__restrict__ dst = MGX_TB_UNI(dst_);
+  MgxGeom g;
+  g.n1 = MGX_TB_UNI(g_.n1); g.n2 = MGX_TB_UNI(g_.n2); g.n3 = MGX_TB_UNI(g_.n3); g.n3g = MGX_TB_UNI(g_.n3g); g.z0 = MGX_TB_UNI(g_.z0);
+  g.px = MGX_TB_UNI(g_.px); g.py = MGX_TB_UNI(g_.py); g.pz = MGX_TB_UNI(g_.pz); g.front = MGX_TB_UNI(g_.front);
+  MgxSweepParams<T> p;
+  p.s1 = MGX_TB_UNI(p_.s1); p.s2 = MGX_TB_UNI(p_.s2);
+#pragma unroll
+  for (int i = 0; i < 3; ++i) { p.a[i] = MGX_TB_UNI(p_.a[i]); p.w[i] = MGX_TB_UNI(p_.w[i]); }
+  const MgxBox *__restrict__ bx = MGX_TB_UNI(bx_);
+  const int nb = MGX_TB_UNI(nb_), tx0 = MGX_TB_UNI(tx0_), ty0 = MGX_TB_UNI(ty0_), zc0 = MGX_TB_UNI(zc0_), zc1 = MGX_TB_UNI(zc1_);
+  const int reduce = MGX_TB_UNI(reduce_), n_commit = MGX_TB_UNI(n_commit_);
+  u64 *__restrict__ res = MGX_TB_UNI(res_);
   typedef typename MgxVec2<T>::type V2;
   constexpr int TXP = 64;
   constexpr int HP = NS;                   // halo pairs on either side of a row
@@ -71,10 +132,10 @@ __device__ __forceinline__ void mgx_tb_body(const T *__restrict__ src, T *__rest
   constexpr int R = HALO ? 2 : RW;         // items (pairs) of a lane
   constexpr int L = 2 * NS - 1;            // last stage
   constexpr int NP = L + 2;                // register sets of planes k+1 .. k-L
-  static_assert(LR % NW == 0 && NW % 2 == 0, "rows of a wave must share the parity of y");
+  static_assert(LR % NW == 0, "the staged rows must divide over the row waves");
   static_assert(LR % 2 == 0 && (LR / 2) * 2 * HP <= 64, "the halo pairs of two rows per lane must fit one wave");
-  static_assert(DF == 1 || DF == 2, "one or two planes in flight");
-  auto A = [&](int stage, int buf, int i) -> T & { return lds[(stage * 2 + buf) * PL + i]; };
+  static_assert(DF == 1, "one plane in flight");
+  auto A = [&](int stage, int buf, int i) __attribute__((always_inline)) -> T & { return lds[(stage * 2 + buf) * PL + i]; };
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
 
   // ---- items: branch-free per item; what must not be touched is masked by value selects, its loads go to the
@@ -89,7 +150,7 @@ __device__ __forceinline__ void mgx_tb_body(const T *__restrict__ src, T *__rest
   for (int j = 0; j < R; ++j) {
     int r, pc;
     bool valid;
-    if (!HALO) { r = wave + NW * j; pc = HP + lane; valid = true; }
+    if (!HALO) { r = strip * RW + j; pc = HP + lane; valid = true; }
     else {
       const int sel = lane % (2 * HP);
       r = 2 * (lane / (2 * HP)) + j;
@@ -161,39 +222,47 @@ __device__ __forceinline__ void mgx_tb_body(const T *__restrict__ src, T *__rest
       for (int i = 0; i < 6; ++i) bl->wtab[t][m][i] = r[i] / s;
     }
   }
-  auto zset = [&](int zglob) -> unsigned {       // boxes whose z range holds the global plane
+  auto zset = [&](int zglob) __attribute__((always_inline)) -> unsigned {       // boxes whose z range holds the global plane
     return BOXES ? (unsigned)__ballot(blo2 <= zglob && zglob <= bhi2) : 0u;
   };
 
   const long long pzl = g.pz;
   const int k0 = zc0 - L;                        // first step: stage 0 on the lowest plane of the grown chunk
   const int zmin = -1, zmax = g.n3 + 2;          // planes of the allocation
-  auto fetch = [&](V2 (&w)[R], int z) {
+  auto fetch = [&](V2 (&w)[R], int z) __attribute__((always_inline)) {
     z = z < zmin ? zmin : z > zmax ? zmax : z;   // past the allocation: any plane, the data are not used
     const char *pb = reinterpret_cast<const char *>(src + pzl * (z + 1));
 #pragma unroll
     for (int j = 0; j < R; ++j) w[j] = *reinterpret_cast<const V2 *>(pb + gob[j]);
   };
 
-  V2 P[NP][R];                                   // P[i] = plane k + 1 - i
-  V2 F[DF][R];                                   // planes in flight
+  // The register window of planes k+1 .. k-L.  It moves down one plane per step; so that it is copied once per TWO
+  // steps, it lives in W[0 .. NP]: at unroll position 0 plane k+1-i is W[i+1] and the plane in flight (k+2) is loaded
+  // into W[0]; at position 1 plane k+1-i is W[i] and the plane in flight goes to FF; after that step every set moves
+  // down by two (W[i] = W[i-2], W[1] = FF).
+  V2 W[NP + 1][R];
+  V2 FF[R];
   T below[R];                                    // plane k - L - 1: the cell under the one the last stage updates
 #pragma unroll
-  for (int i = 0; i < NP; ++i)
+  for (int i = 0; i <= NP; ++i)
 #pragma unroll
-    for (int j = 0; j < R; ++j) P[i][j].x = P[i][j].y = (T)0;
+    for (int j = 0; j < R; ++j) W[i][j].x = W[i][j].y = (T)0;
 #pragma unroll
-  for (int j = 0; j < R; ++j) below[j] = (T)0;
-  fetch(P[2], k0 - 1);
-  fetch(P[1], k0);
-  fetch(P[0], k0 + 1);
-  if (DF == 2) fetch(F[1], k0 + 2);
+  for (int j = 0; j < R; ++j) { below[j] = (T)0; FF[j].x = FF[j].y = (T)0; }
+  fetch(W[3], k0 - 1);
+  fetch(W[2], k0);
+  fetch(W[1], k0 + 1);
 
-#define MGX_TBQ(u, j) (((P0) + (u) + (HALO ? (j) : 0)) & 1)   /* position updated by every stage at unroll position u */
+#define MGX_TBQ(u, j) (((P0) + (u) + (j)) & 1)   /* position in pair j that every stage updates at unroll position u */
 #define MGX_CMP(v, q) ((q) ? (v).y : (v).x)
+  static_assert(EDGE == 0 || (!HALO && RW >= 2 * NS + 1), "an edge strip holds the ring rows and at least one row of the tile");
+  // does half-sweep S update row j of this wave's strip (staged rows S + 1 .. LR - 2 - S)?  does anybody read what the
+  // strip passes on to half-sweep S in LDS (rows S .. LR - 1 - S)?  Compile-time once j is unrolled.
+#define MGX_NEED(S, j) (EDGE == 0 || (EDGE == 1 ? (j) >= (S) + 1 : (j) <= RW - 2 - (S)))
+#define MGX_NEEDW(S, j) (EDGE == 0 || (EDGE == 1 ? (j) >= (S) : (j) <= RW - 1 - (S)))
   // raw red cells of plane k0 for stage 0 of the first step (red sits where black does not)
 #pragma unroll
-  for (int j = 0; j < R; ++j) A(0, 0, li[j]) = MGX_CMP(P[1][j], 1 - MGX_TBQ(0, j));
+  for (int j = 0; j < R; ++j) A(0, 0, li[j]) = MGX_CMP(W[2][j], 1 - MGX_TBQ(0, j));
 
   unsigned zs[L + 3];                            // Z sets of planes k+1 .. k-L-1 (global)
 #pragma unroll
@@ -215,7 +284,7 @@ __device__ __forceinline__ void mgx_tb_body(const T *__restrict__ src, T *__rest
       xyany |= (xs4.x | xs4.y | xs4.z | xs4.w) & (ys4.x | ys4.y | ys4.z);
     }
   }
-  auto plane_codes = [&](unsigned (&out)[R], const unsigned zl, const unsigned zc, const unsigned zh) {
+  auto plane_codes = [&](unsigned (&out)[R], const unsigned zl, const unsigned zc, const unsigned zh) __attribute__((always_inline)) {
     const uint4 xs4 = bl->xq[pcs];
 #pragma unroll
     for (int j = 0; j < R; ++j) {
@@ -233,17 +302,186 @@ __device__ __forceinline__ void mgx_tb_body(const T *__restrict__ src, T *__rest
   bool rowin[R];
 #pragma unroll
   for (int j = 0; j < R; ++j) {
-    const int r_ = __builtin_amdgcn_readfirstlane(wave) + NW * j;
+    const int r_ = strip * RW + j;
     rowin[j] = !HALO && r_ >= 2 * NS && r_ <= LR - 1 - 2 * NS;
   }
 
-  // one step: U = unroll position (parity of k - k0)
-  auto step = [&](auto Uc, const int k) {
+#ifndef MGX_TB_SHIFT2
+#define MGX_TB_SHIFT2 0                          /* the window moves two planes every second step (1) or one plane every step (0) */
+#endif
+#ifndef MGX_TB_FAST
+#define MGX_TB_FAST 0                            /* FREE row waves run the mask-free step where they can */
+#endif
+#if MGX_TB_SHIFT2
+#define MGX_PW(i) W[(i) + 1 - U]                  /* plane k + 1 - i at unroll position U */
+#define MGX_FETCH_INTO_W0 (U == 0)
+#define MGX_SHIFT_NOW (U == 1)
+#define MGX_SHIFT_BY 2
+#else
+#define MGX_PW(i) W[(i) + 1]
+#define MGX_FETCH_INTO_W0 true
+#define MGX_SHIFT_NOW true
+#define MGX_SHIFT_BY 1
+#endif
+  // ---- the mask-free step (FAST): one block of straight-line code ----
+  // A FREE row wave runs it on the steps on which every stage works inside its own z range and inside the level
+  // (kf_lo .. kf_hi below): no plane-range tests, no flag tests, the stores through a buffer descriptor of the plane
+  // whose range check drops the pairs that are not the tile's own (offset beyond the plane), the reductions without
+  // selects (one max |dV| per item, looked at per row at the end; rows that do not count get their |V| masked to a
+  // value that adds exactly nothing by one AND with a wave-uniform mask).  Nothing in it depends on a condition, so
+  // the compiler is free to issue a stage's LDS reads under the arithmetic of the stage before.
+#ifdef MGX_TB_STAMPS      /* experiment builds: where the cycles of a step go (printed by one block) */
+  unsigned long long stamp_acc[6] = {0, 0, 0, 0, 0, 0}, stamp_prev = 0;
+#define MGX_STAMP(i) { __builtin_amdgcn_sched_barrier(0); unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); \
+                       __builtin_amdgcn_sched_barrier(0); if (i >= 0) stamp_acc[i < 0 ? 0 : i] += t_ - stamp_prev; stamp_prev = t_; }
+#else
+#define MGX_STAMP(i)
+#endif
+  T errj[R];
+  unsigned smask[R];                             // 0x7fffffff for the rows of the tile proper, 0 for the others (uniform)
+  unsigned stoff[R];                             // byte offset of the pair inside its plane if it is stored, else out of range
+#pragma unroll
+  for (int j = 0; j < R; ++j) {
+    errj[j] = (T)0;
+    smask[j] = 0u;
+    stoff[j] = st[j] ? gob[j] : 0x80000000u;
+  }
+  const unsigned plane_bytes = (unsigned)((g.pz + g.front) * (long long)sizeof(T));   // < 2^31 (mgx_fused_supported)
+  typedef unsigned mgx_u4 __attribute__((ext_vector_type(4)));
+  typedef unsigned mgx_u2 __attribute__((ext_vector_type(2)));
+  auto fast_step = [&](auto Uc, auto REDc, const int k) __attribute__((always_inline)) {
     constexpr int U = decltype(Uc)::value;
+    constexpr int RED = decltype(REDc)::value;
+    MGX_STAMP(-1)
+#ifndef MGX_TB_FAST_MEM
+#define MGX_TB_FAST_MEM 2                        /* experiment builds: 0 flat loads and stores, 1 buffer loads, 2 buffer loads and stores */
+#endif
+    if constexpr (MGX_TB_FAST_MEM == 0) {
+      if constexpr (MGX_FETCH_INTO_W0) fetch(W[0], k + 2); else fetch(FF, k + 2);
+    } else {                                     // plane k + 2 into the set that is free at this position
+      int z = k + 2;
+#ifdef MGX_TB_ABLATE_FIXEDPLANE     /* timing experiment: every step loads the same plane (cache hits) */
+      z = zc0;
+#endif
+      z = z < zmin ? zmin : z > zmax ? zmax : z;
+      const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+          const_cast<T *>(src + pzl * (z + 1)), 0, (int)plane_bytes, 0x00020000);
+#pragma unroll
+      for (int j = 0; j < R; ++j) {
+        V2 t_;
+        if constexpr (sizeof(T) == 8) {
+          const mgx_u4 r_ = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)gob[j], 0, 0);
+          t_.x = __hiloint2double((int)r_.y, (int)r_.x);
+          t_.y = __hiloint2double((int)r_.w, (int)r_.z);
+        } else {
+          const mgx_u2 r_ = __builtin_amdgcn_raw_buffer_load_b64(rs, (int)gob[j], 0, 0);
+          t_.x = __uint_as_float(r_.x);
+          t_.y = __uint_as_float(r_.y);
+        }
+        if constexpr (MGX_FETCH_INTO_W0) W[0][j] = t_; else FF[j] = t_;
+      }
+    }
+    auto stage = [&](auto Sc) __attribute__((always_inline)) {
+      constexpr int S = decltype(Sc)::value;
+      T other[R];
+#pragma unroll
+      for (int j = 0; j < R; ++j) other[j] = A(S, U, li[j] + (2 * MGX_TBQ(U, j) - 1));
+      const T vylo = A(S, U, li[0] - LP), vyhi = A(S, U, li[R - 1] + LP);
+#pragma unroll
+      for (int j = 0; j < R; ++j) {
+        const int q = MGX_TBQ(U, j);
+        const T vc = MGX_CMP(MGX_PW(S + 1)[j], q), partner = MGX_CMP(MGX_PW(S + 1)[j], 1 - q);
+        const T zhi = MGX_CMP(MGX_PW(S)[j], q);
+        T zlo;
+        if constexpr (S == L) zlo = below[j]; else zlo = MGX_CMP(MGX_PW(S + 2)[j], q);
+        // the rows of a lane are neighbours: the cells at y - 1 and y + 1 (the other colour, the same position in
+        // their pairs) sit in the lane's own registers, except under the first and above the last row
+        const T vym = j == 0 ? vylo : MGX_CMP(MGX_PW(S + 1)[j > 0 ? j - 1 : 0], q);
+        const T vyp = j == R - 1 ? vyhi : MGX_CMP(MGX_PW(S + 1)[j < R - 1 ? j + 1 : R - 1], q);
+        const T vv = p.s1 * vc + p.s2 * mgx_avg_uniform<T>(partner, other[j], vym, vyp, zlo, zhi, p.w);
+        if (q) MGX_PW(S + 1)[j].y = vv; else MGX_PW(S + 1)[j].x = vv;
+        if constexpr (S >= L - 1 && (RED & 1) != 0) errj[j] = mgx_max_abs(errj[j], vv - vc);
+        if constexpr (S >= L - 1 && (RED & 2) != 0) {
+          const double v_ = (double)vv;
+          const unsigned h_ = (unsigned)__double2hiint(v_) & smask[j];
+          const unsigned t_ = sizeof(T) == 8 ? h_ : (mgx_abs_top(vv) & smask[j]);
+          topmax = t_ > topmax ? t_ : topmax;
+          mgx_fast_sum_add(fh, fl2, __hiloint2double((int)h_, __double2loint(v_)));
+        }
+      }
+      if constexpr (S == L && MGX_TB_FAST_MEM < 2) {
+        char *pb = reinterpret_cast<char *>(dst + pzl * (k - L + 1));
+#pragma unroll
+        for (int j = 0; j < R; ++j)
+          if (st[j]) {
+            typedef T nv2 __attribute__((ext_vector_type(2)));
+            nv2 o_;
+            o_.x = MGX_PW(L + 1)[j].x;
+            o_.y = MGX_PW(L + 1)[j].y;
+            __builtin_nontemporal_store(o_, reinterpret_cast<nv2 *>(pb + gob[j]));
+          }
+      }
+      if constexpr (S == L && MGX_TB_FAST_MEM == 2) {
+        const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(dst + pzl * (k - L + 1), 0, (int)plane_bytes,
+                                                                            0x00020000);
+#pragma unroll
+        for (int j = 0; j < R; ++j) {
+          if constexpr (sizeof(T) == 8) {
+            mgx_u4 o_;
+            o_.x = (unsigned)__double2loint(MGX_PW(L + 1)[j].x); o_.y = (unsigned)__double2hiint(MGX_PW(L + 1)[j].x);
+            o_.z = (unsigned)__double2loint(MGX_PW(L + 1)[j].y); o_.w = (unsigned)__double2hiint(MGX_PW(L + 1)[j].y);
+            __builtin_amdgcn_raw_buffer_store_b128(o_, rd, (int)stoff[j], 0, 2 /* nt */);
+          } else {
+            mgx_u2 o_;
+            o_.x = __float_as_uint(MGX_PW(L + 1)[j].x); o_.y = __float_as_uint(MGX_PW(L + 1)[j].y);
+            __builtin_amdgcn_raw_buffer_store_b64(o_, rd, (int)stoff[j], 0, 2 /* nt */);
+          }
+        }
+      }
+    };
+    stage(std::integral_constant<int, 0>{});
+    stage(std::integral_constant<int, 1>{});
+    if constexpr (NS > 1) {
+      stage(std::integral_constant<int, 2>{});
+      stage(std::integral_constant<int, 3>{});
+    }
+    MGX_STAMP(0)
+#pragma unroll
+    for (int j = 0; j < R; ++j) {
+      const int q = MGX_TBQ(U, j);
+#pragma unroll
+      for (int sgl = 0; sgl <= L; ++sgl) A(sgl, 1 - U, li[j]) = MGX_CMP(MGX_PW(sgl)[j], q);
+      below[j] = MGX_CMP(MGX_PW(L + 1)[j], 1 - q);
+    }
+    MGX_STAMP(1)
+    MGX_TB_SYNC();
+    MGX_STAMP(2)
+#ifdef MGX_TB_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    MGX_STAMP(3)
+#endif
+    if constexpr (MGX_SHIFT_NOW) {
+#pragma unroll
+      for (int i = NP; i >= MGX_SHIFT_BY; --i)
+#pragma unroll
+        for (int j = 0; j < R; ++j) W[i][j] = W[i - MGX_SHIFT_BY][j];
+      if constexpr (MGX_SHIFT_BY == 2) {
+#pragma unroll
+        for (int j = 0; j < R; ++j) W[1][j] = FF[j];
+      }
+    }
+  };
+
+  // one step: U = unroll position (parity of k - k0)
+  auto step = [&](auto Uc, const int k) __attribute__((always_inline)) {
+    constexpr int U = decltype(Uc)::value;
+    MGX_STAMP(-1)
 #ifdef MGX_TB_ABLATE_BITS
     if (!(reduce & 128))
 #endif
-    fetch(F[DF == 2 ? U : 0], k + 1 + DF);
+    {
+      if constexpr (MGX_FETCH_INTO_W0) fetch(W[0], k + 2); else fetch(FF, k + 2);
+    }
     bool boxy = false;
     if (BOXES) {
       unsigned zor = 0u;
@@ -268,7 +506,7 @@ __device__ __forceinline__ void mgx_tb_body(const T *__restrict__ src, T *__rest
       }
     }
 
-    auto stage = [&](auto Sc) {
+    auto stage = [&](auto Sc) __attribute__((always_inline)) {
       constexpr int S = decltype(Sc)::value;
       if constexpr (HALO && S == L) return;      // the last stage works on the tile proper: no halo pair
       const int z = k - S, zg = z + g.z0;
@@ -277,18 +515,28 @@ __device__ __forceinline__ void mgx_tb_body(const T *__restrict__ src, T *__rest
         bool actv[R];
 #pragma unroll
         for (int j = 0; j < R; ++j) {
-          other[j] = A(S, U, li[j] + (2 * MGX_TBQ(U, j) - 1));
-          vym[j] = A(S, U, li[j] - LP);
-          vyp[j] = A(S, U, li[j] + LP);
+          other[j] = (T)0; vym[j] = (T)0; vyp[j] = (T)0; vold[j] = (T)0; cnew[j] = (T)0; actv[j] = false;
+          if (MGX_NEED(S, j)) other[j] = A(S, U, li[j] + (2 * MGX_TBQ(U, j) - 1));
+        }
+        // the rows of a lane are neighbours: the cells at y - 1 and y + 1 (the other colour, the same position in
+        // their pairs, which this stage does not touch) sit in the lane's own registers, except under the first and
+        // above the last row
+        if (MGX_NEED(S, 0)) vym[0] = A(S, U, li[0] - LP);
+        if (MGX_NEED(S, R - 1)) vyp[R - 1] = A(S, U, li[R - 1] + LP);
+#pragma unroll
+        for (int j = 0; j < R; ++j) {
+          if (j > 0) vym[j] = MGX_CMP(MGX_PW(S + 1)[j > 0 ? j - 1 : 0], MGX_TBQ(U, j));
+          if (j < R - 1) vyp[j] = MGX_CMP(MGX_PW(S + 1)[j < R - 1 ? j + 1 : R - 1], MGX_TBQ(U, j));
         }
 #pragma unroll
         for (int j = 0; j < R; ++j) {
+          if (!MGX_NEED(S, j)) continue;         // (compile time)
           const int q = MGX_TBQ(U, j);
           actv[j] = FREE || (fl[j] & (1u << (2 * S + q))) != 0u;
-          const T vc = MGX_CMP(P[S + 1][j], q), partner = MGX_CMP(P[S + 1][j], 1 - q);
-          const T zhi = MGX_CMP(P[S][j], q);
+          const T vc = MGX_CMP(MGX_PW(S + 1)[j], q), partner = MGX_CMP(MGX_PW(S + 1)[j], 1 - q);
+          const T zhi = MGX_CMP(MGX_PW(S)[j], q);
           T zlo;
-          if constexpr (S == L) zlo = below[j]; else zlo = MGX_CMP(P[S + 2][j], q);
+          if constexpr (S == L) zlo = below[j]; else zlo = MGX_CMP(MGX_PW(S + 2)[j], q);
           T vv;
           if (BOXES != 0 && boxy) {
             vv = mgx_cell_from_code<T, BOXES>((cc[S][j] >> (16 * q)) & 0xffffu, vc, q ? partner : other[j],
@@ -300,21 +548,21 @@ __device__ __forceinline__ void mgx_tb_body(const T *__restrict__ src, T *__rest
           }
           vold[j] = vc;
           cnew[j] = FREE ? vv : (actv[j] ? vv : vc);
-          if (q) P[S + 1][j].y = cnew[j]; else P[S + 1][j].x = cnew[j];
+          if (q) MGX_PW(S + 1)[j].y = cnew[j]; else MGX_PW(S + 1)[j].x = cnew[j];
         }
         if constexpr (S == L) {
           char *pb = reinterpret_cast<char *>(dst + pzl * (z + 1));
 #pragma unroll
           for (int j = 0; j < R; ++j)
 #ifdef MGX_TB_ABLATE_BITS
-            if (st[j] && !(reduce & 64)) {
+            if (MGX_NEED(S, j) && st[j] && !(reduce & 64)) {
 #else
-            if (st[j]) {
+            if (MGX_NEED(S, j) && st[j]) {
 #endif
               typedef T nv2 __attribute__((ext_vector_type(2)));
               nv2 o_;
-              o_.x = P[L + 1][j].x;
-              o_.y = P[L + 1][j].y;
+              o_.x = MGX_PW(L + 1)[j].x;
+              o_.y = MGX_PW(L + 1)[j].y;
               __builtin_nontemporal_store(o_, reinterpret_cast<nv2 *>(pb + gob[j]));
             }
         }
@@ -324,6 +572,8 @@ __device__ __forceinline__ void mgx_tb_body(const T *__restrict__ src, T *__rest
             double a_[R];
 #pragma unroll
             for (int j = 0; j < R; ++j) {
+              a_[j] = 0.0;
+              if (!MGX_NEED(S, j)) continue;     // (compile time)
               const int q = MGX_TBQ(U, j);
               const bool urow = zown && rowin[j];
               const T d_ = cnew[j] - vold[j];                        // 0 where nothing was updated
@@ -333,7 +583,11 @@ __device__ __forceinline__ void mgx_tb_body(const T *__restrict__ src, T *__rest
               const unsigned t_ = counts ? mgx_abs_top(cnew[j]) : 0u;
               topmax = t_ > topmax ? t_ : topmax;
             }
-            if (reduce & 2) mgx_sum_items<R>(a_, fh, fl2);
+            if (reduce & 2) {
+#pragma unroll
+              for (int j = 0; j < R; ++j)
+                if (MGX_NEED(S, j)) mgx_fast_sum_add(fh, fl2, a_[j]);
+            }
           }
         }
       }
@@ -344,9 +598,10 @@ __device__ __forceinline__ void mgx_tb_body(const T *__restrict__ src, T *__rest
       stage(std::integral_constant<int, 2>{});
       stage(std::integral_constant<int, 3>{});
     }
+    MGX_STAMP(0)
     // What the next step's stages read in LDS, written after all reads of this step (a stage's result stays in the
-    // register window, so no stage's reads wait behind another stage's writes): stage s + 1 gets the cells stage s
-    // updated on plane k - s, stage 0 the raw red cells of plane k + 1.  (A stage that skipped its plane passes on
+    // register window, so no stage's reads wait behind another stage's writes): stage s gets the cells stage s - 1
+    // updated on plane k - s + 1, stage 0 the raw red cells of plane k + 1.  (A stage that skipped its plane passes on
     // cells nobody reads.)  Then the cell under the last stage's next cell.
 #pragma unroll
     for (int j = 0; j < R; ++j) {
@@ -356,20 +611,30 @@ __device__ __forceinline__ void mgx_tb_body(const T *__restrict__ src, T *__rest
 #else
       {
 #endif
-        A(0, 1 - U, li[j]) = MGX_CMP(P[0][j], q);
 #pragma unroll
-        for (int sgl = 0; sgl < L; ++sgl) A(sgl + 1, 1 - U, li[j]) = MGX_CMP(P[sgl + 1][j], q);
+        for (int sgl = 0; sgl <= L; ++sgl)
+          if (MGX_NEEDW(sgl, j)) A(sgl, 1 - U, li[j]) = MGX_CMP(MGX_PW(sgl)[j], q);
       }
-      below[j] = MGX_CMP(P[L + 1][j], 1 - q);
+      if (MGX_NEED(L, j)) below[j] = MGX_CMP(MGX_PW(L + 1)[j], 1 - q);
     }
+    MGX_STAMP(1)
     MGX_TB_SYNC();
-    // the window moves down one plane
+    MGX_STAMP(2)
+#ifdef MGX_TB_STAMPS
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    MGX_STAMP(3)
+#endif
+    // the window moves down two planes every second step
+    if constexpr (MGX_SHIFT_NOW) {
 #pragma unroll
-    for (int i = NP - 1; i >= 1; --i)
+      for (int i = NP; i >= MGX_SHIFT_BY; --i)
 #pragma unroll
-      for (int j = 0; j < R; ++j) P[i][j] = P[i - 1][j];
+        for (int j = 0; j < R; ++j) W[i][j] = W[i - MGX_SHIFT_BY][j];
+      if constexpr (MGX_SHIFT_BY == 2) {
 #pragma unroll
-    for (int j = 0; j < R; ++j) P[0][j] = F[DF == 2 ? 1 - U : 0][j];
+        for (int j = 0; j < R; ++j) W[1][j] = FF[j];
+      }
+    }
     if (BOXES) {
 #pragma unroll
       for (int i = L + 2; i >= 1; --i) zs[i] = zs[i - 1];
@@ -384,13 +649,52 @@ __device__ __forceinline__ void mgx_tb_body(const T *__restrict__ src, T *__rest
 
   static_assert(2 * 2 * R * MGX_FLUSH_GROUPS <= MGX_FAST_SUM_CELLS, "partial sums must stay exact between two flushes");
   int turns = 0;
+  const int kend = zc1 + L;
+  // steps on which a FREE row wave may run the mask-free step: past the 2 L steps in which the stages start one after
+  // the other, before the last step (its stage L - 1 works on plane zc1 + 1, which is not the tile's own), and with
+  // stage 0 (plane k) inside the level
+  constexpr bool HAS_FAST = MGX_TB_FAST != 0 && FREE && !HALO && BOXES == 0 && EDGE == 0;
+  const int kf_lo = k0 + 2 * L, kf_hi = min(kend - 1, g.n3g - g.z0);
+  if constexpr (HAS_FAST) {
+#pragma unroll
+    for (int j = 0; j < R; ++j) smask[j] = rowin[j] ? 0x7fffffffu : 0u;
+  }
+  auto run = [&](auto REDc) __attribute__((always_inline)) {
 #pragma clang loop unroll(disable)
-  for (int kb = k0; kb <= zc1 + L; kb += 2) {
-    step(std::integral_constant<int, 0>{}, kb);
-    if (kb + 1 <= zc1 + L) step(std::integral_constant<int, 1>{}, kb + 1);
-    if (!HALO && (reduce & 2) && (++turns % MGX_FLUSH_GROUPS) == 0) mgx_fast_sum_flush(fh, fl2, slo, shi);
+    for (int kb = k0; kb <= kend; kb += 2) {
+      if (HAS_FAST && kb >= kf_lo && kb + 1 <= kf_hi) {
+        if constexpr (HAS_FAST) {
+          fast_step(std::integral_constant<int, 0>{}, REDc, kb);
+          fast_step(std::integral_constant<int, 1>{}, REDc, kb + 1);
+        }
+      } else {
+        step(std::integral_constant<int, 0>{}, kb);
+        if (kb + 1 <= kend) step(std::integral_constant<int, 1>{}, kb + 1);
+      }
+      if (!HALO && (reduce & 2) && (++turns % MGX_FLUSH_GROUPS) == 0) mgx_fast_sum_flush(fh, fl2, slo, shi);
+    }
+  };
+  if constexpr (HAS_FAST) {
+    if ((reduce & 3) == 0) run(std::integral_constant<int, 0>{});
+    else if ((reduce & 3) == 1) run(std::integral_constant<int, 1>{});
+    else run(std::integral_constant<int, 3>{});
+#pragma unroll
+    for (int j = 0; j < R; ++j) err = mgx_max_abs(err, rowin[j] ? errj[j] : (T)0);
+  } else {
+    run(std::integral_constant<int, 0>{});
   }
   if (!HALO && (reduce & 2)) mgx_fast_sum_flush(fh, fl2, slo, shi);
+#ifdef MGX_TB_STAMPS
+  if (blockIdx.x == 300 && lane == 0)
+    printf("wave %d halo %d free %d steps %d: stages %llu  lds-writes %llu  barrier %llu  vmcnt %llu  (cycles of the 100 MHz counter x 21)\n", wave, (int)HALO,
+           (int)FREE, kend - k0 + 1, stamp_acc[0], stamp_acc[1], stamp_acc[2], stamp_acc[3]);
+#endif
+#undef MGX_NEED
+#undef MGX_NEEDW
+#undef MGX_PW
+#undef MGX_FETCH_INTO_W0
+#undef MGX_SHIFT_NOW
+#undef MGX_SHIFT_BY
 #undef MGX_TBQ
 #undef MGX_CMP
   if (reduce & 2) {                              // uniform over the block
@@ -402,7 +706,79 @@ __device__ __forceinline__ void mgx_tb_body(const T *__restrict__ src, T *__rest
       mgx_block_exact_sum<T>(dst, g, tx0, min(tx0 + 2 * TXP - 1, g.n1), ty0, min(ty0 + TY - 1, g.n2), zc0, zc1, slo, shi, ovf);
     }
   }
-  if (reduce & 3) mgx_block_commit<NW + 1>((double)(err * err), slo, shi, ovf, reduce & 3, res, n_commit);
+  if (reduce & 3) mgx_block_commit<MGX_TB_WAVES(NW)>((double)(err * err), slo, shi, ovf, reduce & 3, res, n_commit);
+}
+
+// ---- the wave that loads nothing for itself ----
+// A wave waits for the plane it loaded at the start of a step before the step ends (the window moves on), so a step
+// cannot take less than one trip to memory; once the arithmetic of a step is shorter than that trip, the trip paces
+// the whole block.  One more wave per block therefore touches every 128-byte line of the tile's plane a few steps
+// before the others load it, with loads whose results nobody waits for: the planes the working waves ask for are in
+// the L2 cache by then.  It takes part in every barrier and in the reductions' hand-off (with nothing to add).
+
+template <typename T, int NS, int TY, int NW>
+__device__ __attribute__((noinline)) void mgx_tb_prefetch_wave(const T *__restrict__ src_, T *__restrict__ dst_, const MgxGeom g_,
+                                                               const int tx0_, const int ty0_, const int zc0_, const int zc1_,
+                                                               const int reduce_, u64 *__restrict__ res_,
+                                                               MgxBoxLds<T> *__restrict__ bl, const int n_commit_) {
+  typedef int mgx_i4 __attribute__((ext_vector_type(4)));
+  constexpr int L = 2 * NS - 1;
+  constexpr int LR = TY + 4 * NS;
+  constexpr int ROW_BYTES = (64 + 2 * NS) * 2 * (int)sizeof(T);             // staged pairs of a row
+  constexpr int LINES = (ROW_BYTES + 127 + 127) / 128;                      // lines a row can touch (any alignment)
+  constexpr int NLOAD = (LR * LINES + 63) / 64;
+  const T *__restrict__ src = mgx_uni(src_);
+  T *__restrict__ dst = mgx_uni(dst_);
+  MgxGeom g;
+  g.n1 = mgx_uni(g_.n1); g.n2 = mgx_uni(g_.n2); g.n3 = mgx_uni(g_.n3); g.n3g = mgx_uni(g_.n3g); g.z0 = mgx_uni(g_.z0);
+  g.px = mgx_uni(g_.px); g.py = mgx_uni(g_.py); g.pz = mgx_uni(g_.pz); g.front = mgx_uni(g_.front);
+  const int tx0 = mgx_uni(tx0_), ty0 = mgx_uni(ty0_), zc0 = mgx_uni(zc0_), zc1 = mgx_uni(zc1_);
+  const int reduce = mgx_uni(reduce_), n_commit = mgx_uni(n_commit_);
+  u64 *__restrict__ res = mgx_uni(res_);
+  const int lane = threadIdx.x & 63;
+  const unsigned plane_bytes = (unsigned)((g.pz + g.front) * (long long)sizeof(T));
+  unsigned off[NLOAD];                           // byte offset of "my" lines inside a plane; out of range = none
+#pragma unroll
+  for (int i = 0; i < NLOAD; ++i) {
+    const int idx = lane + 64 * i, r = idx / LINES, ln = idx % LINES;
+    const int y = ty0 - 2 * NS + r;
+    const long long row0 = (g.front + (long long)(tx0 - 2 * NS - 1) + (long long)g.px * y) * (long long)sizeof(T);
+    const long long b = (row0 & ~127ll) + 128ll * ln;
+    const bool ok = r < LR && y >= 0 && y <= g.n2 + 1 && b >= 0 && b < row0 + ROW_BYTES && b + 4 <= (long long)plane_bytes;
+    off[i] = ok ? (unsigned)b : 0x80000000u;
+  }
+  const int k0 = zc0 - L, kend = zc1 + L;
+  auto touch = [&](int z) __attribute__((always_inline)) {
+    if (z < -1 || z > g.n3 + 2) return;          // uniform
+    const unsigned long long base = (unsigned long long)(src + g.pz * (long long)(z + 1));
+    mgx_i4 rs;
+    rs.x = (int)(unsigned)(base & 0xffffffffull);
+    rs.y = (int)(unsigned)((base >> 32) & 0xffffull);
+    rs.z = (int)plane_bytes;
+    rs.w = 0x00020000;
+#pragma unroll
+    for (int i = 0; i < NLOAD; ++i) {
+      unsigned t_;                               // never read: nobody waits for these loads
+      asm volatile("buffer_load_dword %0, %1, %2, 0 offen" : "=v"(t_) : "v"(off[i]), "s"(rs) : "memory");
+    }
+  };
+#pragma unroll
+  for (int a = 0; a < MGX_TB_PREFETCH_AHEAD; ++a) touch(k0 + 2 + a);
+  __syncthreads();                               // the barrier of the working waves before their first step
+#pragma clang loop unroll(disable)
+  for (int k = k0; k <= kend; ++k) {
+    if (k + 2 + MGX_TB_PREFETCH_AHEAD <= kend + 1) touch(k + 2 + MGX_TB_PREFETCH_AHEAD);
+    MGX_TB_SYNC();
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  u64 slo = 0, shi = 0;
+  unsigned ovf = 0;
+  if (reduce & 2) {
+    __syncthreads();
+    if (bl->big != 0u)
+      mgx_block_exact_sum<T>(dst, g, tx0, min(tx0 + 127, g.n1), ty0, min(ty0 + TY - 1, g.n2), zc0, zc1, slo, shi, ovf);
+  }
+  if (reduce & 3) mgx_block_commit<MGX_TB_WAVES(NW)>(0.0, slo, shi, ovf, reduce & 3, res, n_commit);
 }
 
 template <typename T, int NS, int TY, int BOXES, int NW, int DF>
@@ -413,22 +789,44 @@ __device__ __forceinline__ void mgx_tb_tile(const T *__restrict__ src, T *__rest
                                             const int n_commit) {
   const int tx = tile % ntx, ty = tile / ntx;
   const int tx0 = 1 + tx * 128, ty0 = 1 + ty * TY;
-  const int wave = threadIdx.x >> 6;
+  const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const bool halo = wave == NW;
+  if (MGX_TB_PREFETCH && wave == NW + 1) {
+    mgx_tb_prefetch_wave<T, NS, TY, NW>(src, dst, g, tx0, ty0, zc0, zc1, reduce, res, bl, n_commit);
+    return;
+  }
+  constexpr int RW = (TY + 4 * NS) / NW;
+  // Strips of rows and waves.  The waves of a block go to the four SIMDs in turn, and of two waves on one SIMD the
+  // older one is served first: the step is paced by the younger ones.  The two strips with less work (the first and
+  // the last: see EDGE) therefore go to the last two row waves, the strips in between to the first ones.
+  constexpr bool EDGES = MGX_TB_EDGE_STRIPS != 0 && BOXES == 0 && NW >= 3 && RW >= 2 * NS + 1;
+  const int strip = !EDGES ? wave : wave == NW - 2 ? 0 : wave == NW - 1 ? NW - 1 : wave + 1;
   // position of the black cell (odd x + y + z; pairs start at odd x) of the wave's first item on the plane of the first step
-  const int p0 = (ty0 - 2 * NS + (halo ? 0 : wave) + (zc0 - (2 * NS - 1)) + g.z0) & 1;
+  const int p0 = (ty0 - 2 * NS + (halo ? 0 : strip * RW) + (zc0 - (2 * NS - 1)) + g.z0) & 1;
   // (see FREE above) staged rows ty0-2NS .. ty0+TY-1+2NS and columns tx0 .. tx0+127 all interior
   const bool free_rows = BOXES == 0 && ty0 - 2 * NS >= 1 && ty0 + TY - 1 + 2 * NS <= g.n2 && tx0 + 127 <= g.n1;
-  if (halo) {
-    if (p0) mgx_tb_body<T, NS, TY, BOXES, NW, DF, 1, true>(src, dst, g, p, bx, nb, tx0, ty0, zc0, zc1, reduce, res, lds, bl, n_commit);
-    else mgx_tb_body<T, NS, TY, BOXES, NW, DF, 0, true>(src, dst, g, p, bx, nb, tx0, ty0, zc0, zc1, reduce, res, lds, bl, n_commit);
-  } else if (BOXES == 0 && free_rows) {
-    if (p0) mgx_tb_body<T, NS, TY, 0, NW, DF, 1, false, true>(src, dst, g, p, bx, nb, tx0, ty0, zc0, zc1, reduce, res, lds, bl, n_commit);
-    else mgx_tb_body<T, NS, TY, 0, NW, DF, 0, false, true>(src, dst, g, p, bx, nb, tx0, ty0, zc0, zc1, reduce, res, lds, bl, n_commit);
-  } else {
-    if (p0) mgx_tb_body<T, NS, TY, BOXES, NW, DF, 1, false>(src, dst, g, p, bx, nb, tx0, ty0, zc0, zc1, reduce, res, lds, bl, n_commit);
-    else mgx_tb_body<T, NS, TY, BOXES, NW, DF, 0, false>(src, dst, g, p, bx, nb, tx0, ty0, zc0, zc1, reduce, res, lds, bl, n_commit);
+#define MGX_TB_CALL(B_, P_, H_, F_, E_) \
+  mgx_tb_body<T, NS, TY, B_, NW, DF, P_, H_, F_, E_>(src, dst, g, p, bx, nb, tx0, ty0, zc0, zc1, reduce, res, lds, bl, n_commit, strip)
+#define MGX_TB_CALL_P(B_, H_, F_, E_) { if (p0) MGX_TB_CALL(B_, 1, H_, F_, E_); else MGX_TB_CALL(B_, 0, H_, F_, E_); }
+  if (halo) MGX_TB_CALL_P(BOXES, true, false, 0)
+  else {
+    bool done = false;
+    if constexpr (EDGES) {
+      if (wave == NW - 2) {
+        if (free_rows) MGX_TB_CALL_P(0, false, true, 1) else MGX_TB_CALL_P(0, false, false, 1)
+        done = true;
+      } else if (wave == NW - 1) {
+        if (free_rows) MGX_TB_CALL_P(0, false, true, 2) else MGX_TB_CALL_P(0, false, false, 2)
+        done = true;
+      }
+    }
+    if (!done) {
+      if (BOXES == 0 && free_rows) MGX_TB_CALL_P(0, false, true, 0)
+      else MGX_TB_CALL_P(BOXES, false, false, 0)
+    }
   }
+#undef MGX_TB_CALL_P
+#undef MGX_TB_CALL
 }
 
 template <typename T, int NS, int TY, int NW>
@@ -437,7 +835,7 @@ constexpr size_t mgx_tb_lds_field() { return (size_t)(2 * NS) * 2 * (64 + 2 * NS
 // `tiles` as for k_fused_sweep: three ints per block (tile column, first and last plane of the z chunk; -1 = padding),
 // in three segments: pieces some box with rho != 1 reaches, pieces only rho = 1 boxes reach, box-free pieces
 template <typename T, int NS, int TY, int NW, int DF>
-__global__ __launch_bounds__((NW + 1) * 64) void k_tb_sweep(const T *__restrict__ src, T *__restrict__ dst, const MgxGeom g,
+__global__ __launch_bounds__(MGX_TB_WAVES(NW) * 64) void k_tb_sweep(const T *__restrict__ src, T *__restrict__ dst, const MgxGeom g,
                                                             const MgxSweepParams<T> p, const MgxBox *__restrict__ bx,
                                                             const int nb, const int ntx, const int *__restrict__ tiles,
                                                             const int n_commit, const int reduce,
@@ -449,9 +847,12 @@ __global__ __launch_bounds__((NW + 1) * 64) void k_tb_sweep(const T *__restrict_
   const int entry = tiles[3 * b], zc0 = tiles[3 * b + 1], zc1 = tiles[3 * b + 2];
   if (entry < 0) return;
   const int cls = entry >> MGX_TILE_CLASS_SHIFT, tile = entry & ((1 << MGX_TILE_CLASS_SHIFT) - 1);
+#ifndef MGX_TB_LEAN_EXPERIMENT      /* (experiment builds: box-free levels only) */
   if (cls == 2) mgx_tb_tile<T, NS, TY, 2, NW, DF>(src, dst, g, p, bx, nb, ntx, tile, zc0, zc1, reduce, res, lds, bl, n_commit);
   else if (cls == 1) mgx_tb_tile<T, NS, TY, 1, NW, DF>(src, dst, g, p, bx, nb, ntx, tile, zc0, zc1, reduce, res, lds, bl, n_commit);
-  else mgx_tb_tile<T, NS, TY, 0, NW, DF>(src, dst, g, p, bx, nb, ntx, tile, zc0, zc1, reduce, res, lds, bl, n_commit);
+  else
+#endif
+  mgx_tb_tile<T, NS, TY, 0, NW, DF>(src, dst, g, p, bx, nb, ntx, tile, zc0, zc1, reduce, res, lds, bl, n_commit);
 }
 
 template <typename T, int NS, int TY, int NW, int DF>
@@ -470,7 +871,7 @@ static int mgx_tb_launch_cfg(const MgxFusedPlan &pl, const T *src, T *dst, const
   const MgxTileList &tl = pl.list[0];
   const int total = tl.n_box + tl.n_const + tl.n_fast;
   if (total > 0)
-    hipLaunchKernelGGL((k_tb_sweep<T, NS, TY, NW, DF>), dim3((unsigned)total), dim3((NW + 1) * 64), lds, st, src, dst, g, p, bx,
+    hipLaunchKernelGGL((k_tb_sweep<T, NS, TY, NW, DF>), dim3((unsigned)total), dim3(MGX_TB_WAVES(NW) * 64), lds, st, src, dst, g, p, bx,
                        nb, pl.ntx, pl.d_tiles + 3 * tl.offset, (reduce & 3) ? tl.n_real : 0, reduce, res);
   return 0;
 }
