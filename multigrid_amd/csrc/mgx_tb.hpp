@@ -99,10 +99,10 @@ template <typename P> __device__ __forceinline__ P *mgx_uni(P *const v) { return
 #else
 #define MGX_TB_BODY_ATTR __forceinline__
 #endif
-// EDGE: which strip of rows a row wave owns: 1 the lowest rows of the staged region, 2 the highest, 0 one in between.
-// Half-sweep s works on the staged rows s + 1 .. LR - 2 - s, so the first and the last strip hold rows that only the
-// early half-sweeps need: those waves leave out the rows a stage does not need, at compile time.
-template <typename T, int NS, int TY, int BOXES, int NW, int DF, int P0, bool HALO, bool FREE = false, int EDGE = 0>
+// ROW0: the first staged row of the wave's strip where that is known at compile time (the strips at either end of the
+// staged region), else -1.  Half-sweep s works on the staged rows s + 1 .. LR - 2 - s, so the strips at the ends hold
+// rows that only the early half-sweeps need: those waves leave out the rows a stage does not need, at compile time.
+template <typename T, int NS, int TY, int BOXES, int NW, int DF, int P0, bool HALO, bool FREE = false, int ROW0 = -1>
 __device__ MGX_TB_BODY_ATTR void mgx_tb_body(const T *__restrict__ src_, T *__restrict__ dst_, const MgxGeom g_,
                                             const MgxSweepParams<T> p_, const MgxBox *__restrict__ bx_, const int nb_,
                                             const int tx0_, const int ty0_, const int zc0_, const int zc1_,
@@ -255,11 +255,11 @@ __device__ MGX_TB_BODY_ATTR void mgx_tb_body(const T *__restrict__ src_, T *__re
 
 #define MGX_TBQ(u, j) (((P0) + (u) + (j)) & 1)   /* position in pair j that every stage updates at unroll position u */
 #define MGX_CMP(v, q) ((q) ? (v).y : (v).x)
-  static_assert(EDGE == 0 || (!HALO && RW >= 2 * NS + 1), "an edge strip holds the ring rows and at least one row of the tile");
+  static_assert(ROW0 < 0 || !HALO, "the wave of the halo pairs holds every row");
   // does half-sweep S update row j of this wave's strip (staged rows S + 1 .. LR - 2 - S)?  does anybody read what the
   // strip passes on to half-sweep S in LDS (rows S .. LR - 1 - S)?  Compile-time once j is unrolled.
-#define MGX_NEED(S, j) (EDGE == 0 || (EDGE == 1 ? (j) >= (S) + 1 : (j) <= RW - 2 - (S)))
-#define MGX_NEEDW(S, j) (EDGE == 0 || (EDGE == 1 ? (j) >= (S) : (j) <= RW - 1 - (S)))
+#define MGX_NEED(S, j) (ROW0 < 0 || (ROW0 + (j) >= (S) + 1 && ROW0 + (j) <= LR - 2 - (S)))
+#define MGX_NEEDW(S, j) (ROW0 < 0 || (ROW0 + (j) >= (S) && ROW0 + (j) <= LR - 1 - (S)))
   // raw red cells of plane k0 for stage 0 of the first step (red sits where black does not)
 #pragma unroll
   for (int j = 0; j < R; ++j) A(0, 0, li[j]) = MGX_CMP(W[2][j], 1 - MGX_TBQ(0, j));
@@ -653,7 +653,7 @@ __device__ MGX_TB_BODY_ATTR void mgx_tb_body(const T *__restrict__ src_, T *__re
   // steps on which a FREE row wave may run the mask-free step: past the 2 L steps in which the stages start one after
   // the other, before the last step (its stage L - 1 works on plane zc1 + 1, which is not the tile's own), and with
   // stage 0 (plane k) inside the level
-  constexpr bool HAS_FAST = MGX_TB_FAST != 0 && FREE && !HALO && BOXES == 0 && EDGE == 0;
+  constexpr bool HAS_FAST = MGX_TB_FAST != 0 && FREE && !HALO && BOXES == 0 && ROW0 < 0;
   const int kf_lo = k0 + 2 * L, kf_hi = min(kend - 1, g.n3g - g.z0);
   if constexpr (HAS_FAST) {
 #pragma unroll
@@ -796,35 +796,46 @@ __device__ __forceinline__ void mgx_tb_tile(const T *__restrict__ src, T *__rest
     return;
   }
   constexpr int RW = (TY + 4 * NS) / NW;
-  // Strips of rows and waves.  The waves of a block go to the four SIMDs in turn, and of two waves on one SIMD the
-  // older one is served first: the step is paced by the younger ones.  The two strips with less work (the first and
-  // the last: see EDGE) therefore go to the last two row waves, the strips in between to the first ones.
-  constexpr bool EDGES = MGX_TB_EDGE_STRIPS != 0 && BOXES == 0 && NW >= 3 && RW >= 2 * NS + 1;
-  const int strip = !EDGES ? wave : wave == NW - 2 ? 0 : wave == NW - 1 ? NW - 1 : wave + 1;
+  // Strips of rows and waves.  The NE strips at either end of the staged region hold ring rows, which the later
+  // half-sweeps do not need: less work (see ROW0).  The waves of a block go to the four SIMDs in turn, so the light
+  // strips go to the last row waves, one to a SIMD, the strips in between to the first ones in order.
+  constexpr int NE = (2 * NS + RW - 1) / RW;
+  constexpr bool EDGES = MGX_TB_EDGE_STRIPS != 0 && NE <= 2 && NW >= 2 * NE + 1;
+  const int eidx = wave - (NW - 2 * NE);         // which of the 2 NE light strips, if >= 0
+  int strip = wave;
+  if (EDGES) {
+    if (eidx < 0) strip = wave + NE;
+    else if (NE == 1) strip = eidx == 0 ? 0 : NW - 1;
+    else strip = eidx == 0 ? 1 : eidx == 1 ? NW - 2 : eidx == 2 ? 0 : NW - 1;
+  }
   // position of the black cell (odd x + y + z; pairs start at odd x) of the wave's first item on the plane of the first step
   const int p0 = (ty0 - 2 * NS + (halo ? 0 : strip * RW) + (zc0 - (2 * NS - 1)) + g.z0) & 1;
   // (see FREE above) staged rows ty0-2NS .. ty0+TY-1+2NS and columns tx0 .. tx0+127 all interior
   const bool free_rows = BOXES == 0 && ty0 - 2 * NS >= 1 && ty0 + TY - 1 + 2 * NS <= g.n2 && tx0 + 127 <= g.n1;
-#define MGX_TB_CALL(B_, P_, H_, F_, E_) \
-  mgx_tb_body<T, NS, TY, B_, NW, DF, P_, H_, F_, E_>(src, dst, g, p, bx, nb, tx0, ty0, zc0, zc1, reduce, res, lds, bl, n_commit, strip)
-#define MGX_TB_CALL_P(B_, H_, F_, E_) { if (p0) MGX_TB_CALL(B_, 1, H_, F_, E_); else MGX_TB_CALL(B_, 0, H_, F_, E_); }
-  if (halo) MGX_TB_CALL_P(BOXES, true, false, 0)
+#define MGX_TB_CALL(B_, P_, H_, F_, R0_) \
+  mgx_tb_body<T, NS, TY, B_, NW, DF, P_, H_, F_, R0_>(src, dst, g, p, bx, nb, tx0, ty0, zc0, zc1, reduce, res, lds, bl, n_commit, strip)
+#define MGX_TB_CALL_P(B_, H_, F_, R0_) { if (p0) MGX_TB_CALL(B_, 1, H_, F_, R0_); else MGX_TB_CALL(B_, 0, H_, F_, R0_); }
+#define MGX_TB_CALL_EDGE(R0_) { if (BOXES == 0 && free_rows) MGX_TB_CALL_P(0, false, true, (R0_)) else MGX_TB_CALL_P(BOXES, false, false, (R0_)) }
+  if (halo) MGX_TB_CALL_P(BOXES, true, false, -1)
   else {
     bool done = false;
     if constexpr (EDGES) {
-      if (wave == NW - 2) {
-        if (free_rows) MGX_TB_CALL_P(0, false, true, 1) else MGX_TB_CALL_P(0, false, false, 1)
+      if (eidx >= 0) {
         done = true;
-      } else if (wave == NW - 1) {
-        if (free_rows) MGX_TB_CALL_P(0, false, true, 2) else MGX_TB_CALL_P(0, false, false, 2)
-        done = true;
+        if constexpr (NE == 1) {
+          if (eidx == 0) MGX_TB_CALL_EDGE(0) else MGX_TB_CALL_EDGE((NW - 1) * RW)
+        } else {
+          if (eidx == 0) MGX_TB_CALL_EDGE(RW) else if (eidx == 1) MGX_TB_CALL_EDGE((NW - 2) * RW)
+          else if (eidx == 2) MGX_TB_CALL_EDGE(0) else MGX_TB_CALL_EDGE((NW - 1) * RW)
+        }
       }
     }
     if (!done) {
-      if (BOXES == 0 && free_rows) MGX_TB_CALL_P(0, false, true, 0)
-      else MGX_TB_CALL_P(BOXES, false, false, 0)
+      if (BOXES == 0 && free_rows) MGX_TB_CALL_P(0, false, true, -1)
+      else MGX_TB_CALL_P(BOXES, false, false, -1)
     }
   }
+#undef MGX_TB_CALL_EDGE
 #undef MGX_TB_CALL_P
 #undef MGX_TB_CALL
 }

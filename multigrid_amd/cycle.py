@@ -121,16 +121,21 @@ class Solver:
     def tolerance(self, g) -> float:       # grid_tolerance, t_mg.f90:857-868
         return self.t(G.grid_tolerance(g))
 
-    def gs_steps(self, g, nsteps: int, want_sum: bool, fetch: bool = True, defer: bool = False):
+    def gs_steps(self, g, nsteps: int, want_sum: bool, fetch: bool = True, defer: bool = False, want_err: bool = True):
         """`nsteps` × gs_step (m_gs_CDS.F90:296-315); returns the grid_sum after the last one if asked.
         grid%err = sqrt(max dV^2) of the last sweep.  With fetch=False the sweeps are only enqueued: the level keeps
-        its result record until it is swept again, and grid%err is read from it when somebody asks (level_err)."""
+        its result record until it is swept again, and grid%err is read from it when somebody asks (level_err).
+        want_err=False (only with fetch=False): nobody will read grid%err of these sweeps before the level is swept
+        again (an inner leg of a cycle): the sweeps run without reductions and grid%err keeps its last value."""
         if nsteps <= 0:
             return self.grid_sum(g) if want_sum else None
         g.itt += nsteps
         self.total_sweeps += nsteps
         if self.total_sweeps > self.max_sweeps:
             raise G.MgStop(f"more than {self.max_sweeps} sweeps")
+        if not want_err and not want_sum and not fetch:
+            g.dev.sweep(nsteps, 0)
+            return None
         g.dev.sweep(nsteps, lib.RED_ERR | (lib.RED_SUM if want_sum else 0))
         if not (fetch or want_sum) or defer:     # defer: the caller reads the result later (fetch_deferred)
             g.err_pending = True
@@ -291,8 +296,9 @@ class Solver:
             self.record(grid, 1, tol, new_sum)
             self.say(f"      {'  ' * grid.layer}{grid.steps:6d} {float(tol):10.7f} {float(new_sum * nr):10.7f}")
             return new_sum
-        # nobody reads the residual of an inner leg: its sweeps are enqueued without waiting for them
-        return self.gs_steps(grid, grid.steps, want_sum, fetch=False, defer=defer)
+        # nobody reads the residual of an inner leg (the reference evaluates it only to print it): its sweeps are
+        # enqueued without reductions and without waiting for them; the last leg of a cycle carries both
+        return self.gs_steps(grid, grid.steps, want_sum, fetch=False, defer=defer, want_err=want_sum)
 
     def gs_V(self, pg, cg):
         """m_gs_CDS.F90:220-294.  A cycle holds no host decision (when the print-only sums are off), so from its
