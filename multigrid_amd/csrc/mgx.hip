@@ -13,6 +13,7 @@
 #define MGX_MAIN_UNIT
 #include "mgx_kernels.hpp"
 #include "mgx_plan.hpp"
+#include "mgx_lex.hpp"
 
 // ------------------------------------------------------------------------------------------------
 // errors
@@ -62,7 +63,7 @@ static __device__ __align__(256) u64 scratch[MGX_NOALLOC_MAX_BLOCKS * MGX_NOALLO
 static u64 *g_scratch_ptr[MGX_MAX_DEVICES] = {nullptr};
 
 static unsigned long long g_level_uid = 0;   // the next level's uid
-static int mgx_lex_tiled = 1;    // the reference-order sweep by tile hyperplanes (1) or by cell hyperplanes (0)
+static int mgx_lex_tiled = 2;    // the reference-order sweep: 2 all tiles in one launch (k_lex_chain), 1 a launch per tile hyperplane, 0 per cell hyperplane
 static int mgx_pair_pass = -1;   // 0: never two sweeps per pass, 1: wherever the kernel applies, -1: where it pays (default)
 
 // ------------------------------------------------------------------------------------------------
@@ -117,6 +118,10 @@ struct mgx_level {
   MgxFusedPlan plan;           // tile lists of the fused sweep (rebuilt when the boxes change)
   MgxFusedPlan plan2;          // tile lists of the two-sweeps-per-pass kernel
   std::vector<struct MgxTransferPlan *> transfers;   // index tables of transfers INTO this level, by source geometry
+  // k_lex_chain: the tiles in dispatch order and one counter per tile (both in d_lex), the number of sweeps counted
+  int *d_lex = nullptr;
+  int lex_nt[3] = {0, 0, 0};
+  int lex_epoch = 0;
 };
 
 // device index tables of one (source geometry, method, direction) transfer into a level; they depend on the
@@ -462,6 +467,7 @@ extern "C" int mgx_level_destroy(mgx_level *lv) {
   (void)hipFree(lv->buf[1]);
   (void)hipFree(lv->d_res);
   if (lv->d_solve) (void)hipFree(lv->d_solve);
+  if (lv->d_lex) (void)hipFree(lv->d_lex);
   if (lv->d_boxes) (void)hipFree(lv->d_boxes);
   if (lv->plan.d_tiles) (void)hipFree(lv->plan.d_tiles);
   if (lv->plan2.d_tiles) (void)hipFree(lv->plan2.d_tiles);
@@ -669,30 +675,70 @@ static int sync_shell(mgx_level *lv) {
   return MGX_OK;
 }
 
-// Two sweeps per pass pay where chunks of 64 planes (six extra steps and eight extra planes per chunk) of 128 x 22
-// tiles still fill the compute units twice over: undivided levels of about 400^3 cells and more (measured: 512^3
-// 0.67 ms per pair against 0.86 ms for two passes; 256^3 slower than two passes).
+// Two sweeps per pass pay on undivided levels from about 256^3 cells (measured per sweep, error reduction on the last
+// one: 512^3 0.27 ms against 0.44 ms, 384^3 0.14 against 0.21, 256^3 0.065 against 0.072; 128^3 loses, 0.041 against
+// 0.023: too few pieces for the compute units, and every piece runs six steps more than it has planes).
 template <typename T>
 static bool pair_pass_wanted(const mgx_level *lv) {
   const MgxGeom &g = lv->g;
   const int k = lv->ctx->kernel;
   if (mgx_pair_pass == 0 || k == MGX_KERNEL_FUSED || g.n3 != g.n3g || !mgx_fused_supported<T>(g, lv->nbox)) return false;
   if (mgx_pair_pass == 1 || k == MGX_KERNEL_PAIR) return true;
-  const long long pieces = (long long)((g.n1 + 127) / 128) * ((g.n2 + 21) / 22) * (g.n3 / 64);
-  return pieces >= 512;
+  return (long long)g.n1 * g.n2 * g.n3 >= 12000000LL && g.n1 >= 96 && g.n2 >= 44 && g.n3 >= 32;
 }
 
 // one sweep in the reference's order (k_lex_plane): a launch per hyperplane x + y + z = d, d = 3 .. n1 + n2 + n3; the
 // planes that hold a cell of hyperplane d are d - n1 - n2 .. d - 2, so only the (x, y) blocks that can hold one are
 // launched.  The reductions follow the cleared-replicas protocol: max (vv - V)^2 from the sweep, the sum from a pass of
 // k_abs_sum behind it.
+// tiles of k_lex_chain in dispatch order (hyperplanes I + J + K of the tile grid, x fastest inside one) and their
+// counters, zeroed; built on the first sweep of a level in the reference's order
+template <typename T>
+static int lex_chain_tables(mgx_level *lv) {
+  const MgxGeom &g = lv->g;
+  constexpr int TX = 128 / (int)sizeof(T);
+  const int ntx = (g.n1 + TX - 1) / TX, nty = (g.n2 + MGX_LEXC_CY - 1) / MGX_LEXC_CY, ntz = (g.n3 + MGX_LEXC_CZ - 1) / MGX_LEXC_CZ;
+  const long long nt = (long long)ntx * nty * ntz;
+  std::vector<int> tab;
+  tab.reserve((size_t)(2 * nt));
+  for (int D = 0; D <= ntx + nty + ntz - 3; ++D)
+    for (int K = std::max(0, D - (ntx - 1) - (nty - 1)); K <= std::min(D, ntz - 1); ++K)
+      for (int J = std::max(0, D - K - (ntx - 1)); J <= std::min(D - K, nty - 1); ++J)
+        tab.push_back((D - K - J) | (J << 10) | (K << 20));
+  if ((long long)tab.size() != nt) return fail(MGX_EHIP, "mgx_level_sweep: tile order of the reference-order sweep");
+  tab.resize((size_t)(2 * nt), 0);                     // the counters
+  HIP_TRY(hipMalloc((void **)&lv->d_lex, sizeof(int) * tab.size()));
+  HIP_TRY(hipMemcpyAsync(lv->d_lex, tab.data(), sizeof(int) * tab.size(), hipMemcpyHostToDevice, C(lv)->stream));
+  HIP_TRY(hipStreamSynchronize(C(lv)->stream));          // `tab` goes out of scope
+  lv->lex_nt[0] = ntx; lv->lex_nt[1] = nty; lv->lex_nt[2] = ntz;
+  lv->lex_epoch = 0;
+  return MGX_OK;
+}
+
 template <typename T>
 static int lex_sweep(mgx_level *lv, int reduce) {
   const MgxGeom &g = lv->g;
   hipStream_t st = C(lv)->stream;
   if (reduce) TRY(reset_result(lv));
   const MgxSweepParams<T> p = make_params<T>(lv);
-  if (mgx_lex_tiled) {      // tile hyperplanes (k_lex_tile); MGX_LEX_TILED=0 selects the cell hyperplanes (k_lex_plane)
+  constexpr int CTX = 128 / (int)sizeof(T);
+  const bool chain = mgx_lex_tiled == 2 && lv->nbox <= 32 && (g.n1 + CTX - 1) / CTX < 1024 && (g.n2 + MGX_LEXC_CY - 1) / MGX_LEXC_CY < 1024 &&
+                     (g.n3 + MGX_LEXC_CZ - 1) / MGX_LEXC_CZ < 1024 && (long long)sizeof(T) * (MGX_LEXC_CZ + 2) * g.pz < 0x7fffffffLL;
+  if (chain) {                // every tile in one launch, each waiting for its three predecessors (k_lex_chain)
+    if (!lv->d_lex) {
+      NOT_WHILE_CAPTURING(C(lv), "mgx_level_sweep (the first sweep in the reference's order builds the tile order)");
+      TRY(lex_chain_tables<T>(lv));
+    }
+    const long long nt = (long long)lv->lex_nt[0] * lv->lex_nt[1] * lv->lex_nt[2];
+    const int epoch = ++lv->lex_epoch;
+    if (lv->nbox > 0)
+      hipLaunchKernelGGL((k_lex_chain<T, true>), dim3((unsigned)nt), dim3(64), 0, st, (T *)lv->buf[lv->cur], g, p, lv->d_boxes,
+                         lv->nbox, lv->d_lex, lv->d_lex + nt, epoch, lv->lex_nt[0], lv->lex_nt[1], reduce & MGX_RED_ERR, lv->d_res);
+    else
+      hipLaunchKernelGGL((k_lex_chain<T, false>), dim3((unsigned)nt), dim3(64), 0, st, (T *)lv->buf[lv->cur], g, p, lv->d_boxes,
+                         lv->nbox, lv->d_lex, lv->d_lex + nt, epoch, lv->lex_nt[0], lv->lex_nt[1], reduce & MGX_RED_ERR, lv->d_res);
+  } else
+  if (mgx_lex_tiled) {      // a launch per tile hyperplane (k_lex_tile); MGX_LEX_TILED=0 selects the cell hyperplanes (k_lex_plane)
     const int ntx = (g.n1 + MGX_LEX_TX - 1) / MGX_LEX_TX, nty = (g.n2 + MGX_LEX_TY - 1) / MGX_LEX_TY,
               ntz = (g.n3 + MGX_LEX_TZ - 1) / MGX_LEX_TZ;
     for (int D = 0; D <= ntx + nty + ntz - 3; ++D) {
@@ -957,6 +1003,9 @@ static int fetch_result(mgx_level *lv, double *err, double *sum, uint64_t limbs_
   HIP_TRY(hipMemcpyAsync(c->h_res, lv->d_res, MGX_RES_WORDS * sizeof(u64), hipMemcpyDeviceToHost, c->stream));
   HIP_TRY(hipStreamSynchronize(c->stream));
   const u64 *r = c->h_res;
+  if (r[MGX_RES_ERRWORD] != 0)
+    return fail(MGX_EHIP, "a sweep in the reference's order gave up waiting for a tile before it (level %d): the field of "
+                "this level is not valid", lv->layer);
   if (err) { double e; memcpy(&e, &r[0], 8); *err = e; }
   unsigned __int128 v = 0;
   for (int k = 3; k >= 0; --k) v = (v << 32) + r[1 + k];   // digits may exceed 32 bits: plain positional sum

@@ -1,0 +1,257 @@
+// The reference's own sweep order (gs, m_gs_CDS.F90:317-345: in place, z outermost, x innermost) in ONE launch per
+// sweep.  The level is cut into tiles of one 128-byte line x 8 rows x 8 planes; a tile needs the new values of the
+// tiles before it in x, y and z and the old ones of the tiles behind it, exactly as a cell does.  k_lex_tile launches
+// the tile hyperplanes I + J + K = D one after the other (190 launches at 512^3); here all tiles are one grid,
+// dispatched in hyperplane order, one wave per tile, and a tile waits for its three predecessors through a counter
+// per tile: every sweep adds one to the counter of every tile, so "done in sweep e" reads "counter >= e" and nothing
+// is reset between sweeps.  Blocks are dispatched in index order and a tile only waits for tiles earlier in that
+// order, so the wait ends; should it not (a bound of polls), the tile gives up, raises the error word of the level's
+// result record and still counts itself, so that the launch drains.
+//
+// Hand-off between workgroups inside one launch (other compute units, other L2 slices): the producing wave stores its
+// rows whole 128-byte lines at a time with sc1 stores, waits for them (vmcnt(0)) and then adds to its counter with an
+// agent-scope atomic; the consuming wave polls the counters with agent-scope loads, passes a barrier, and loads the
+// three faces its predecessors wrote with sc1 loads of 4 or 16 bytes.  Everything else a tile reads (its own cells and
+// the faces towards x+1, y+1, z+1) was written before this launch: plain loads, issued before the wait.
+#pragma once
+
+#include <type_traits>
+
+#include "mgx_kernels.hpp"
+
+#define MGX_LEXC_CY 8
+#define MGX_LEXC_CZ 8
+#define MGX_LEXC_MAXSPIN (1 << 19)       /* polls before a tile gives up (each takes a microsecond or more) */
+#define MGX_RES_ERRWORD 6                /* word of the result record a kernel raises when it had to give up */
+
+template <typename T>
+struct MgxLexcBoxLds {
+  unsigned xs[128 / sizeof(T) + 2], ys[MGX_LEXC_CY + 2], zs[MGX_LEXC_CZ + 2];
+  T wtab[2][64][6];
+  unsigned short code[MGX_LEXC_CZ * MGX_LEXC_CY * (128 / sizeof(T))];
+};
+
+typedef unsigned mgx_lx_u4 __attribute__((ext_vector_type(4)));
+
+// `order`: the tiles in dispatch order, I | J << 10 | K << 20.  `done`: one counter per tile, index I + ntx (J + nty K).
+template <typename T, bool BOXED>
+__global__ __launch_bounds__(64) void k_lex_chain(T *__restrict__ V, const MgxGeom g, const MgxSweepParams<T> p,
+                                                  const MgxBox *__restrict__ bx, const int nb,
+                                                  const int *__restrict__ order, int *__restrict__ done,
+                                                  const int epoch, const int ntx, const int nty, const int reduce,
+                                                  u64 *__restrict__ res) {
+  constexpr int TX = 128 / (int)sizeof(T), TY = MGX_LEXC_CY, TZ = MGX_LEXC_CZ;
+  constexpr int PX = TX + 3, PY = (TY + 2) * PX;          // pitches of the staged tile (row, plane), in elements
+  constexpr int WPE = (int)sizeof(T) / 4;                  // 32-bit words per element
+  __shared__ T t[(TZ + 2) * PY];
+  __shared__ MgxBox sbx[BOXED ? 32 : 1];
+  __shared__ typename std::conditional<BOXED, MgxLexcBoxLds<T>, char>::type bl_[1];
+  const int lane = threadIdx.x;
+  const int ent = order[blockIdx.x];
+  const int I = ent & 1023, J = (ent >> 10) & 1023, K = (ent >> 20) & 1023;
+  const int x0 = I * TX + 1, y0 = J * TY + 1, z0 = K * TZ + 1;
+  const int nx = min(TX, g.n1 - x0 + 1), ny = min(TY, g.n2 - y0 + 1), nz = min(TZ, g.n3 - z0 + 1);
+  const int self = I + ntx * (J + nty * K);
+  T err = (T)0;
+  if (BOXED && lane < nb) sbx[lane] = bx[lane];
+
+  // ---- what was written before this launch: own cells and the faces towards x+1, y+1, z+1 (plain loads) ----
+  {
+    const T *const org = V + g.idx(x0 - 1, y0 - 1, z0 - 1);
+    constexpr int RW = TX + 1, BATCH = 8, NB = ((TY + 1) * (TZ + 1) * RW + 64 * BATCH - 1) / (64 * BATCH);
+#pragma unroll 1
+    for (int b = 0; b < NB; ++b) {
+      T tmp[BATCH];
+      int at[BATCH];
+#pragma unroll
+      for (int u = 0; u < BATCH; ++u) {
+        const int e = (b * BATCH + u) * 64 + lane;
+        const int xx = e % RW + 1, r = e / RW, yy = r % (TY + 1) + 1, zz = r / (TY + 1) + 1;   // 1 .. n + 1
+        const bool ok = xx < nx + 2 && yy < ny + 2 && zz < nz + 2;
+        at[u] = ok ? zz * PY + yy * PX + xx : -1;
+        tmp[u] = ok ? org[xx + (long long)g.px * yy + g.pz * zz] : (T)0;
+      }
+#pragma unroll
+      for (int u = 0; u < BATCH; ++u)
+        if (at[u] >= 0) t[at[u]] = tmp[u];
+    }
+  }
+
+  // ---- wait for the tiles before this one in x, y, z ----
+  bool lost = false;
+  {
+    int want = -1;
+    if (lane == 0 && I > 0) want = self - 1;
+    if (lane == 1 && J > 0) want = self - ntx;
+    if (lane == 2 && K > 0) want = self - ntx * nty;
+    int spins = 0;
+    for (;;) {
+      int v = epoch;
+      if (want >= 0) v = __hip_atomic_load(done + want, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (!__any(v - epoch < 0)) break;
+      // (a tile that finds the error word raised does not wait at all: a launch that lost one tile drains at once)
+      if (++spins > MGX_LEXC_MAXSPIN ||
+          ((spins & 255) == 0 && __hip_atomic_load(res + MGX_RES_ERRWORD, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0ull)) {
+        lost = true;
+        break;
+      }
+      __builtin_amdgcn_s_sleep(2);
+    }
+  }
+  __syncthreads();
+
+  // ---- the three faces the predecessors wrote in this launch: sc1 loads of 4 bytes ----
+  {
+    // face elements: x-1 face (ny nz), y-1 face (nx nz), z-1 face (nx ny); ghosts of the level come the same way
+    const int n_a = ny * nz, n_b = nx * nz, n_c = nx * ny, n_all = n_a + n_b + n_c;
+    const unsigned long long base = (unsigned long long)(V + g.idx(x0 - 1, y0 - 1, z0 - 1));
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+        (void *)base, 0, (int)min((long long)0x7fffffff, (long long)sizeof(T) * ((long long)(TZ + 2) * g.pz)), 0x00020000);
+    constexpr int PER = (TY * TZ + 2 * TX * TZ + 63) / 64;          // TY = TZ: bound of n_all / 64
+#pragma unroll
+    for (int u = 0; u < PER; ++u) {
+      const int e = u * 64 + lane;
+      int xx = 0, yy = 0, zz = 0;
+      const bool ok = e < n_all;
+      if (e < n_a) { xx = 0; yy = e % ny + 1; zz = e / ny + 1; }
+      else if (e < n_a + n_b) { const int f = e - n_a; xx = f % nx + 1; yy = 0; zz = f / nx + 1; }
+      else { const int f = e - n_a - n_b; xx = f % nx + 1; yy = f / nx + 1; zz = 0; }
+      const long long el = xx + (long long)g.px * yy + g.pz * zz;
+      const int off = ok ? (int)(el * (long long)sizeof(T)) : (int)0x7ffffff0;     // beyond the records: not loaded
+      unsigned w[2] = {0u, 0u};
+#pragma unroll
+      for (int h = 0; h < WPE; ++h) w[h] = __builtin_amdgcn_raw_buffer_load_b32(rs, off + 4 * h, 0, 16 /* sc1 */);
+      T val;
+      if constexpr (sizeof(T) == 8) val = __hiloint2double((int)w[1], (int)w[0]); else val = __uint_as_float(w[0]);
+      if (ok) t[zz * PY + yy * PX + xx] = val;
+    }
+  }
+  __syncthreads();
+
+  const int cls = BOXED ? mgx_classify(sbx, nb, x0, x0 + nx - 1, y0, y0 + ny - 1, z0 + g.z0, z0 + nz - 1 + g.z0) : 0;
+  const int j = lane & 7, k = lane >> 3;
+  const bool coded = BOXED && cls != 0;
+  if constexpr (BOXED) {
+    if (coded) {
+      MgxLexcBoxLds<T> &bl = bl_[0];
+      unsigned cmask = 0u, rmask = 0u;
+      for (int b = 0; b < nb; ++b) {
+        cmask |= sbx[b].constant ? (1u << b) : 0u;
+        rmask |= sbx[b].rho_is_one ? 0u : (1u << b);
+      }
+      const unsigned tb0 = rmask & (0u - rmask), tb1 = (rmask ^ tb0) & (0u - (rmask ^ tb0));
+      if (lane < TX + 2 + TY + 2 + TZ + 2) {
+        const int dim = lane < TX + 2 ? 0 : lane < TX + 2 + TY + 2 ? 1 : 2;
+        const int l = dim == 0 ? lane : dim == 1 ? lane - (TX + 2) : lane - (TX + 2 + TY + 2);
+        const int pos = (dim == 0 ? x0 : dim == 1 ? y0 : z0 + g.z0) - 1 + l;
+        unsigned set = 0u;
+        for (int b = 0; b < nb; ++b) set |= (sbx[b].lo[dim] <= pos && pos <= sbx[b].hi[dim]) ? (1u << b) : 0u;
+        (dim == 0 ? bl.xs : dim == 1 ? bl.ys : bl.zs)[l] = set;
+      }
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const int m = lane;
+        const unsigned tb = h ? tb1 : tb0;
+        const T rb = tb ? (T)sbx[__ffs((int)tb) - 1].rho : (T)1;
+        T r[6];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) r[i] = (((m >> i) & 1) ? rb : (T)1) * p.a[i >> 1];
+        T sm = r[0];
+        sm = sm + r[1]; sm = sm + r[2]; sm = sm + r[3]; sm = sm + r[4]; sm = sm + r[5];
+#pragma unroll
+        for (int i = 0; i < 6; ++i) bl.wtab[h][m][i] = r[i] / sm;
+      }
+      __syncthreads();
+      if (j < ny && k < nz) {
+        const uint4 ys4 = make_uint4(bl.ys[j], bl.ys[j + 1], bl.ys[j + 2], 0u);
+        const unsigned zl = bl.zs[k], zc = bl.zs[k + 1], zh = bl.zs[k + 2];
+        for (int i = 0; i < nx; ++i)
+          bl.code[(k * TY + j) * TX + i] =
+              (unsigned short)mgx_cell_code(bl.xs[i + 1], bl.xs[i], bl.xs[i + 2], ys4, zl, zc, zh, cmask, rmask, tb0, tb1);
+      }
+      __syncthreads();
+    }
+  }
+
+  // ---- the tile by its own hyperplanes i + j + k = m: lane = (j, k), every operand in LDS ----
+  const bool mine = j < ny && k < nz;
+  T *c0 = t + (k + 1) * PY + (j + 1) * PX + 1;
+  for (int m = 0; m < nx + ny + nz - 2; ++m) {
+    const int i = m - j - k;
+    if (mine && i >= 0 && i < nx) {
+      T *c = c0 + i;
+      const T vc = c[0];
+      T vv = (T)0;
+      bool have = false;
+      if constexpr (BOXED) {
+        if (coded) {
+          const MgxLexcBoxLds<T> &bl = bl_[0];
+          const unsigned code = bl.code[(k * TY + j) * TX + i];
+          const T *w = &bl.wtab[0][0][0] + (code & 127u) * 6u;
+          T avg = c[-1] * w[0] + c[1] * w[1];
+          avg = avg + c[-PX] * w[2];
+          avg = avg + c[PX] * w[3];
+          avg = avg + c[-PY] * w[4];
+          avg = avg + c[PY] * w[5];
+          if (code & MGX_CODE_GENERAL)
+            avg = mgx_avg_general<T>(c[-1], c[1], c[-PX], c[PX], c[-PY], c[PY], sbx, nb, x0 + i, y0 + j, z0 + k + g.z0, p.a);
+          avg = (code & MGX_CODE_CONST) ? vc : avg;
+          vv = p.s1 * vc + p.s2 * avg;
+          have = true;
+        }
+      }
+      if (!have) vv = p.s1 * vc + p.s2 * mgx_avg_uniform<T>(c[-1], c[1], c[-PX], c[PX], c[-PY], c[PY], p.w);
+      const T dv = vv - vc;
+      const T d2 = dv * dv;
+      err = d2 > err ? d2 : err;
+      c[0] = vv;
+    }
+    __syncthreads();
+  }
+
+  // ---- the tile back: whole lines, 16 bytes a lane, sc1; then the counter ----
+  {
+    const unsigned long long base = (unsigned long long)(V + g.idx(x0, y0, z0));
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+        (void *)base, 0, (int)min((long long)0x7fffffff, (long long)sizeof(T) * ((long long)TZ * g.pz)), 0x00020000);
+    constexpr int EPL = 16 / (int)sizeof(T);             // elements per 16 bytes
+    constexpr int LPR = TX / EPL;                        // lanes per row (8)
+    constexpr int ROWS = 64 / LPR;                       // rows per store instruction (8)
+    const int sub = lane % LPR, rsel = lane / LPR;
+#pragma unroll
+    for (int u = 0; u < TY * TZ / ROWS; ++u) {
+      const int r = u * ROWS + rsel, yy = r % TY, zz = r / TY;
+      const int xx = sub * EPL;
+      const T *srow = t + (zz + 1) * PY + (yy + 1) * PX + 1 + xx;
+      const bool rowok = yy < ny && zz < nz;
+      const long long el = xx + (long long)g.px * yy + g.pz * zz;
+      if (rowok && xx + EPL <= nx) {
+        mgx_lx_u4 o;
+        if constexpr (sizeof(T) == 8) {
+          o.x = (unsigned)__double2loint(srow[0]); o.y = (unsigned)__double2hiint(srow[0]);
+          o.z = (unsigned)__double2loint(srow[1]); o.w = (unsigned)__double2hiint(srow[1]);
+        } else {
+          o.x = __float_as_uint(srow[0]); o.y = __float_as_uint(srow[1]); o.z = __float_as_uint(srow[2]); o.w = __float_as_uint(srow[3]);
+        }
+        __builtin_amdgcn_raw_buffer_store_b128(o, rs, (int)(el * (long long)sizeof(T)), 0, 16 /* sc1 */);
+      } else if (rowok) {                                // the ragged end of a row of the level's last tile in x
+        for (int q = 0; q < EPL; ++q)
+          if (xx + q < nx) {
+            if constexpr (sizeof(T) == 8) {
+              __builtin_amdgcn_raw_buffer_store_b32((unsigned)__double2loint(srow[q]), rs, (int)((el + q) * 8), 0, 16);
+              __builtin_amdgcn_raw_buffer_store_b32((unsigned)__double2hiint(srow[q]), rs, (int)((el + q) * 8 + 4), 0, 16);
+            } else {
+              __builtin_amdgcn_raw_buffer_store_b32(__float_as_uint(srow[q]), rs, (int)((el + q) * 4), 0, 16);
+            }
+          }
+      }
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (lane == 0) {
+    __hip_atomic_fetch_add(done + self, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (lost) __hip_atomic_fetch_or(res + MGX_RES_ERRWORD, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+  if (reduce & 1) mgx_block_commit<1>((double)err, 0ull, 0ull, 0u, 1, res);
+}
