@@ -53,7 +53,7 @@ enum { MGX_INTERP_FULL = 1, MGX_INTERP_HALF = 2 };
 /* which reductions a sweep accumulates */
 enum { MGX_RED_ERR = 1, MGX_RED_SUM = 2 };
 /* the two launches of mgx_level_sweep_part */
-enum { MGX_PART_EDGE = 1, MGX_PART_INNER = 2 };
+enum { MGX_PART_EDGE = 1, MGX_PART_INNER = 2, MGX_PART_EDGE2 = 3, MGX_PART_INNER2 = 4 };   /* ...2: of a pass of two sweeps */
 /* sweep kernel selection (results are bit-identical; for tests and benchmarking): AUTO = the fused kernel, with two
  * sweeps per pass on the levels where that pays; TWO_PASS = one colour per launch, in place; FUSED = black and red
  * in one pass, one sweep per pass everywhere; PAIR = as FUSED, two sweeps per pass wherever that kernel applies.
@@ -136,16 +136,24 @@ int mgx_level_setup(mgx_level *lv, int init);
  * On a slab level one call takes ONE sweep (fused kernel): it reads local planes -1, 0, n3+1, n3+2
  * as the caller left them and updates planes 1..n3; the caller then sends the new planes 1, 2 to
  * the lower neighbour's n3+1, n3+2 and the new planes n3-1, n3 to the upper neighbour's -1, 0
- * (mgx_level_plane_ptr; no other call is needed after such an exchange).  Reductions cover the
- * slab's own planes. */
+ * (mgx_level_plane_ptr; no other call is needed after such an exchange) -- or TWO sweeps in one
+ * pass over the slab (nsweeps = 2; gs_V's legs, m_gs_CDS.F90:240-242), which reads FOUR halo
+ * planes on either side (-3..0, n3+1..n3+4) and is followed by an exchange of four (new planes
+ * 1..4 to the lower neighbour's n3+1..n3+4, n3-3..n3 to the upper neighbour's -3..0): half as many
+ * exchanges and passes over the slab.  Reductions cover the slab's own planes. */
 int mgx_level_sweep(mgx_level *lv, int nsweeps, int reduce);
+/* Does mgx_level_sweep(lv, 2, ...) take the two sweeps in one pass?  On an undivided level that is what the library
+ * will do; on a slab it says whether passes of two sweeps pay (the caller chooses there, by its halo exchange).  No
+ * counterpart in the reference. */
+int mgx_level_pair_pass(mgx_level *lv, int32_t *yes);
 /* The same sweep (one, fused kernel) in two launches, for z slabs that overlap the halo exchange with the bulk
  * of the sweep: MGX_PART_EDGE sweeps the first and the last z chunk (which hold planes 1, 2 and n3-1, n3) and
  * makes the new field the current one (mgx_level_plane_ptr then returns its planes: send 1, 2 and n3-1, n3,
  * receive into -1, 0 and n3+1, n3+2); MGX_PART_INNER sweeps the remaining planes from the same old field and may
  * run while the planes travel.  Every call of the first kind must be followed by one of the second before any
- * other operation on the level.  `reduce` as in mgx_level_sweep, the same value in both calls.  No counterpart in
- * the reference (its sweep runs in one address space). */
+ * other operation on the level.  `reduce` as in mgx_level_sweep, the same value in both calls.  MGX_PART_EDGE2 /
+ * MGX_PART_INNER2 are the two launches of a pass of two sweeps (planes 1..4 and n3-3..n3 lie in the first).  No
+ * counterpart in the reference (its sweep runs in one address space). */
 int mgx_level_sweep_part(mgx_level *lv, int part, int reduce);
 /* one colour only (parity 1 = odd x+y+z, 0 = even), planes [zlo,zhi] (local, 1-based,
  * inclusive) — the building block for halo-exchange overlap across z-slabs.
@@ -207,8 +215,9 @@ int mgx_level_upload(mgx_level *lv, const void *host);
 int mgx_level_download(mgx_level *lv, void *host);
 
 /* z-slab plumbing: device address and byte size of `count` consecutive local planes
- * starting at `z` (valid z: -1 .. n3_local+2; planes are contiguous, rows padded to
- * the device pitch), for halo exchange by the host's communication layer. */
+ * starting at `z` (valid z: -1 .. n3_local+2, on a slab of a decomposed level -3 .. n3_local+4;
+ * planes are contiguous, rows padded to the device pitch), for halo exchange by the host's
+ * communication layer. */
 int mgx_level_plane_ptr(mgx_level *lv, int32_t z, int32_t count, void **ptr, size_t *bytes);
 /* tell the library that planes outside 1..n3_local were rewritten behind its back */
 int mgx_level_halo_written(mgx_level *lv);

@@ -62,6 +62,7 @@ extern "C" const char *mgx_version(void) { return "mgx 0.1 (gfx950)"; }
 static __device__ __align__(256) u64 scratch[MGX_NOALLOC_MAX_BLOCKS * MGX_NOALLOC_REC];   // 512 KiB
 static u64 *g_scratch_ptr[MGX_MAX_DEVICES] = {nullptr};
 
+#define MGX_SLAB_EXTRA 2        /* planes a slab holds beyond -1 and n3 + 2 on either side */
 static unsigned long long g_level_uid = 0;   // the next level's uid
 static int mgx_lex_tiled = 2;    // the reference-order sweep: 2 all tiles in one launch (k_lex_chain), 1 a launch per tile hyperplane, 0 per cell hyperplane
 static int mgx_pair_pass = -1;   // 0: never two sweeps per pass, 1: wherever the kernel applies, -1: where it pays (default)
@@ -96,12 +97,17 @@ struct mgx_level {
   int elem = 8;
   MgxGeom g{};
   long long elems = 0;         // allocated elements per buffer
+  // buf[i] is where plane -1 starts (MgxGeom::idx); a slab of a decomposed level has MGX_SLAB_EXTRA more planes on
+  // either side (alloc[i] = buf[i] - lead elements), so that two sweeps in one pass find four halo planes
+  void *alloc[2] = {nullptr, nullptr};
+  long long lead = 0;
   void *buf[2] = {nullptr, nullptr};
   int cur = 0;
   bool shell_synced = false;   // buf[1-cur] holds the same ghost shell as buf[cur]
   bool defined = false;        // field content is meaningful
   bool inner_pending = false;  // mgx_level_sweep_part: the edge part ran, the inner part is due
   int part_reduce = 0;         // the reductions the edge part was asked for (the inner part must ask for the same)
+  bool part_two = false;       // the edge part was that of a pass of two sweeps
   bool zero_pending = false;   // brought back but not yet zero-filled: the next reader fills, a full overwrite skips it
   // parameters
   double sor = 1.8;
@@ -425,23 +431,26 @@ extern "C" int mgx_level_create_slab(mgx_ctx *ctx, int layer, const int32_t n[3]
   g.py = n[1] + 2;
   g.pz = (long long)g.px * g.py;
   g.front = align;
-  lv->elems = g.front + g.pz * (long long)(n3_local + 4) + align;
+  const bool is_slab = n3_local != n[2];
+  lv->lead = is_slab ? (long long)MGX_SLAB_EXTRA * g.pz : 0;
+  lv->elems = g.front + g.pz * (long long)(n3_local + 4) + align + 2 * lv->lead;
   const size_t bytes = (size_t)lv->elems * elem_bytes;
   for (int i = 0; i < 2; ++i) {
-    hipError_t e = hipMalloc(&lv->buf[i], bytes);
+    hipError_t e = hipMalloc(&lv->alloc[i], bytes);
     if (e != hipSuccess) {
-      if (i) (void)hipFree(lv->buf[0]);
+      if (i) (void)hipFree(lv->alloc[0]);
       delete lv;
       return fail(MGX_ENOMEM, "mgx_level_create: hipMalloc(%zu) failed: %s", bytes, hipGetErrorString(e));
     }
+    lv->buf[i] = (char *)lv->alloc[i] + (size_t)lv->lead * elem_bytes;
   }
   hipError_t e = hipMalloc((void **)&lv->d_res, MGX_RES_TOTAL_WORDS * sizeof(u64));
-  if (e != hipSuccess) { (void)hipFree(lv->buf[0]); (void)hipFree(lv->buf[1]); delete lv; return fail(MGX_ENOMEM, "hipMalloc(result)"); }
-  if (hipMemsetAsync(lv->buf[0], 0, bytes, ctx->stream) != hipSuccess ||
-      hipMemsetAsync(lv->buf[1], 0, bytes, ctx->stream) != hipSuccess ||
+  if (e != hipSuccess) { (void)hipFree(lv->alloc[0]); (void)hipFree(lv->alloc[1]); delete lv; return fail(MGX_ENOMEM, "hipMalloc(result)"); }
+  if (hipMemsetAsync(lv->alloc[0], 0, bytes, ctx->stream) != hipSuccess ||
+      hipMemsetAsync(lv->alloc[1], 0, bytes, ctx->stream) != hipSuccess ||
       hipMemsetAsync(lv->d_res, 0, MGX_RES_TOTAL_WORDS * sizeof(u64), ctx->stream) != hipSuccess) {
     (void)hipStreamSynchronize(ctx->stream);
-    (void)hipFree(lv->buf[0]); (void)hipFree(lv->buf[1]); (void)hipFree(lv->d_res);
+    (void)hipFree(lv->alloc[0]); (void)hipFree(lv->alloc[1]); (void)hipFree(lv->d_res);
     delete lv;
     return fail(MGX_EHIP, "mgx_level_create: zero fill failed");
   }
@@ -463,8 +472,8 @@ extern "C" int mgx_level_destroy(mgx_level *lv) {
   lv->ctx->levels.erase(std::remove(lv->ctx->levels.begin(), lv->ctx->levels.end(), lv), lv->ctx->levels.end());
   (void)hipSetDevice(lv->ctx->device);
   (void)hipStreamSynchronize(lv->ctx->stream);
-  (void)hipFree(lv->buf[0]);
-  (void)hipFree(lv->buf[1]);
+  (void)hipFree(lv->alloc[0]);
+  (void)hipFree(lv->alloc[1]);
   (void)hipFree(lv->d_res);
   if (lv->d_solve) (void)hipFree(lv->d_solve);
   if (lv->d_lex) (void)hipFree(lv->d_lex);
@@ -488,7 +497,7 @@ extern "C" int mgx_level_bring_back(mgx_level *lv) {
 // the zero fill grid_bring_back promised, before anything reads the field
 static int materialize(mgx_level *lv) {
   if (!lv->zero_pending) return MGX_OK;
-  HIP_TRY(hipMemsetAsync(lv->buf[lv->cur], 0, (size_t)lv->elems * lv->elem, C(lv)->stream));
+  HIP_TRY(hipMemsetAsync(lv->alloc[lv->cur], 0, (size_t)lv->elems * lv->elem, C(lv)->stream));
   lv->zero_pending = false;
   return MGX_OK;
 }
@@ -679,18 +688,21 @@ static int sync_shell(mgx_level *lv) {
 // one: 512^3 0.27 ms against 0.44 ms, 384^3 0.14 against 0.21, 256^3 0.065 against 0.072; 128^3 loses, 0.041 against
 // 0.023: too few pieces for the compute units, and every piece runs six steps more than it has planes).
 template <typename T>
+static bool pair_pass_possible(const mgx_level *lv) {
+  const int k = lv->ctx->kernel;
+  return mgx_pair_pass != 0 && k != MGX_KERNEL_FUSED && k != MGX_KERNEL_TWO_PASS && k != MGX_KERNEL_LEX &&
+         mgx_fused_supported<T>(lv->g, lv->nbox);
+}
+// does mgx_level_sweep take two sweeps of this level in one pass where it has the choice (undivided levels)?  On a slab
+// the caller chooses (two sweeps per call need four halo planes): the same rule says whether that pays.
+template <typename T>
 static bool pair_pass_wanted(const mgx_level *lv) {
   const MgxGeom &g = lv->g;
-  const int k = lv->ctx->kernel;
-  if (mgx_pair_pass == 0 || k == MGX_KERNEL_FUSED || g.n3 != g.n3g || !mgx_fused_supported<T>(g, lv->nbox)) return false;
-  if (mgx_pair_pass == 1 || k == MGX_KERNEL_PAIR) return true;
+  if (!pair_pass_possible<T>(lv)) return false;
+  if (mgx_pair_pass == 1 || lv->ctx->kernel == MGX_KERNEL_PAIR) return true;
   return (long long)g.n1 * g.n2 * g.n3 >= 12000000LL && g.n1 >= 96 && g.n2 >= 44 && g.n3 >= 32;
 }
 
-// one sweep in the reference's order (k_lex_plane): a launch per hyperplane x + y + z = d, d = 3 .. n1 + n2 + n3; the
-// planes that hold a cell of hyperplane d are d - n1 - n2 .. d - 2, so only the (x, y) blocks that can hold one are
-// launched.  The reductions follow the cleared-replicas protocol: max (vv - V)^2 from the sweep, the sum from a pass of
-// k_abs_sum behind it.
 // tiles of k_lex_chain in dispatch order (hyperplanes I + J + K of the tile grid, x fastest inside one) and their
 // counters, zeroed; built on the first sweep of a level in the reference's order
 template <typename T>
@@ -777,7 +789,7 @@ static int do_sweeps(mgx_level *lv, int nsweeps, int reduce) {
   if (which == MGX_KERNEL_FUSED && !mgx_fused_supported<T>(g, lv->nbox))
     return fail(MGX_ELIMIT, "mgx_level_sweep: the fused kernel handles at most %d boxes", MGX_MAX_FUSED_BOXES);
   for (int s = 0; s < nsweeps; ++s) {
-    if (which == MGX_KERNEL_FUSED && s + 2 <= nsweeps && pair_pass_wanted<T>(lv)) {
+    if (which == MGX_KERNEL_FUSED && s + 2 <= nsweeps && (g.n3 != g.n3g ? pair_pass_possible<T>(lv) : pair_pass_wanted<T>(lv))) {
       // two sweeps in one pass over the field (gs_V's legs run their sweeps back to back, m_gs_CDS.F90:240-242)
       const int red = (s + 2 == nsweeps) ? reduce : 0;
       if (red) TRY(prepare_single_pass(lv));
@@ -785,7 +797,7 @@ static int do_sweeps(mgx_level *lv, int nsweeps, int reduce) {
       if (!lv->plan2.valid) NOT_WHILE_CAPTURING(C(lv), "mgx_level_sweep (first pair pass of a level builds its tile lists)");
       if (!lv->plan2.valid && make_plan(lv, lv->plan2, 2) != 0)
         return fail(MGX_EHIP, "mgx_level_sweep: could not build the tile lists of the two-sweep kernel");
-      if (mgx_tb2_launch(lv->plan2, (const T *)lv->buf[lv->cur], (T *)lv->buf[1 - lv->cur], g,
+      if (mgx_tb2_launch(lv->plan2, 0, (const T *)lv->buf[lv->cur], (T *)lv->buf[1 - lv->cur], g,
                                                     make_params<T>(lv), lv->d_boxes, lv->nbox, red, lv->d_res,
                                                     C(lv)->stream) != 0)
         return fail(MGX_EHIP, "mgx_level_sweep: two-sweep kernel launch configuration failed");
@@ -822,13 +834,16 @@ extern "C" int mgx_level_sweep(mgx_level *lv, int nsweeps, int reduce) {
   if (!lv->defined) return fail(MGX_ESTATE, "mgx_level_sweep: level %d was released", lv->layer);
   if (lv->inner_pending) return fail(MGX_ESTATE, "mgx_level_sweep: the inner part of a split sweep is still due on level %d", lv->layer);
   if (lv->g.n3 != lv->g.n3g) {
-    // a slab: the fused kernel reads halo planes -1, 0, n3+1, n3+2 as the caller left them; the in-place
-    // kernel would need the neighbour's black planes between the two colours
-    if (nsweeps > 1) return fail(MGX_ESTATE, "mgx_level_sweep: a slab takes one sweep per call (exchange the halo planes in between)");
+    // a slab: the fused kernel reads halo planes -1, 0, n3+1, n3+2 as the caller left them (two sweeps in one pass:
+    // -3 .. 0 and n3+1 .. n3+4); the in-place kernel would need the neighbour's black planes between the two colours
     if (C(lv)->kernel == MGX_KERNEL_TWO_PASS)
       return fail(MGX_ESTATE, "mgx_level_sweep: the two-pass kernel sweeps a slab colour by colour (mgx_level_half_sweep)");
     const bool ok = lv->elem == 4 ? mgx_fused_supported<float>(lv->g, lv->nbox) : mgx_fused_supported<double>(lv->g, lv->nbox);
     if (!ok) return fail(MGX_ELIMIT, "mgx_level_sweep: the fused kernel does not take this level; sweep the slab with mgx_level_half_sweep");
+    const bool pair = lv->elem == 4 ? pair_pass_possible<float>(lv) : pair_pass_possible<double>(lv);
+    if (nsweeps > 2 || (nsweeps == 2 && !pair))
+      return fail(MGX_ESTATE, "mgx_level_sweep: a slab takes one sweep per call, or two in one pass where mgx_level_pair_pass "
+                  "says so (exchange the halo planes in between)");
   }
   TRY(set_device(C(lv)));
   TRY(materialize(lv));
@@ -841,40 +856,59 @@ extern "C" int mgx_level_sweep(mgx_level *lv, int nsweeps, int reduce) {
 template <typename T>
 static int do_sweep_part(mgx_level *lv, int part, int reduce) {
   const MgxGeom &g = lv->g;
+  const bool two = part == MGX_PART_EDGE2 || part == MGX_PART_INNER2;       // two sweeps in one pass
+  const bool edge = part == MGX_PART_EDGE || part == MGX_PART_EDGE2;
   if (!mgx_fused_supported<T>(g, lv->nbox) || C(lv)->kernel == MGX_KERNEL_TWO_PASS || C(lv)->kernel == MGX_KERNEL_LEX)
     return fail(MGX_ESTATE, "mgx_level_sweep_part: needs the fused kernel (at most %d boxes, kernel not forced to two-pass)",
                 MGX_MAX_FUSED_BOXES);
-  if (part == MGX_PART_EDGE) {
+  if (two && !pair_pass_possible<T>(lv))
+    return fail(MGX_ESTATE, "mgx_level_sweep_part: two sweeps per pass are switched off for this context");
+  MgxFusedPlan &pl = two ? lv->plan2 : lv->plan;
+  if (edge) {
     if (lv->inner_pending) return fail(MGX_ESTATE, "mgx_level_sweep_part: the inner part of the previous sweep is still due");
     if (reduce) TRY(prepare_single_pass(lv));
     TRY(sync_shell<T>(lv));
-    if (!lv->plan.valid) NOT_WHILE_CAPTURING(C(lv), "mgx_level_sweep_part (first sweep of a level builds its tile lists)");
-    if (!lv->plan.valid && make_plan(lv, lv->plan, 1) != 0)
-      return fail(MGX_EHIP, "mgx_level_sweep_part: could not build the tile lists of the fused kernel");
-    if (mgx_fused_launch(lv->plan, 1, (const T *)lv->buf[lv->cur], (T *)lv->buf[1 - lv->cur], g, make_params<T>(lv),
-                            lv->d_boxes, lv->nbox, reduce, lv->d_res, C(lv)->stream) != 0)
-      return fail(MGX_EHIP, "mgx_level_sweep_part: fused kernel launch configuration failed");
+    if (!pl.valid) NOT_WHILE_CAPTURING(C(lv), "mgx_level_sweep_part (first sweep of a level builds its tile lists)");
+    if (!pl.valid && make_plan(lv, pl, two ? 2 : 1) != 0)
+      return fail(MGX_EHIP, "mgx_level_sweep_part: could not build the tile lists");
+    const int rc = two ? mgx_tb2_launch(pl, 1, (const T *)lv->buf[lv->cur], (T *)lv->buf[1 - lv->cur], g, make_params<T>(lv),
+                                        lv->d_boxes, lv->nbox, reduce, lv->d_res, C(lv)->stream)
+                       : mgx_fused_launch(pl, 1, (const T *)lv->buf[lv->cur], (T *)lv->buf[1 - lv->cur], g, make_params<T>(lv),
+                                          lv->d_boxes, lv->nbox, reduce, lv->d_res, C(lv)->stream);
+    if (rc != 0) return fail(MGX_EHIP, "mgx_level_sweep_part: kernel launch configuration failed");
     HIP_TRY(hipGetLastError());
     lv->cur = 1 - lv->cur;
     lv->inner_pending = true;
     lv->part_reduce = reduce;
+    lv->part_two = two;
   } else {
     if (!lv->inner_pending) return fail(MGX_ESTATE, "mgx_level_sweep_part: the inner part follows the edge part");
+    if (two != lv->part_two) return fail(MGX_EINVAL, "mgx_level_sweep_part: the inner part of a pass of %d sweeps follows the edge part of one of %d",
+                                         two ? 2 : 1, lv->part_two ? 2 : 1);
     // the blocks of both launches count towards one fold of the reductions (mgx_block_commit)
     if (reduce != lv->part_reduce)
       return fail(MGX_EINVAL, "mgx_level_sweep_part: reduce = %d in the inner part, %d in the edge part", reduce, lv->part_reduce);
-    if (mgx_fused_launch(lv->plan, 2, (const T *)lv->buf[1 - lv->cur], (T *)lv->buf[lv->cur], g, make_params<T>(lv),
-                            lv->d_boxes, lv->nbox, reduce, lv->d_res, C(lv)->stream) != 0)
-      return fail(MGX_EHIP, "mgx_level_sweep_part: fused kernel launch configuration failed");
+    const int rc = two ? mgx_tb2_launch(pl, 2, (const T *)lv->buf[1 - lv->cur], (T *)lv->buf[lv->cur], g, make_params<T>(lv),
+                                        lv->d_boxes, lv->nbox, reduce, lv->d_res, C(lv)->stream)
+                       : mgx_fused_launch(pl, 2, (const T *)lv->buf[1 - lv->cur], (T *)lv->buf[lv->cur], g, make_params<T>(lv),
+                                          lv->d_boxes, lv->nbox, reduce, lv->d_res, C(lv)->stream);
+    if (rc != 0) return fail(MGX_EHIP, "mgx_level_sweep_part: kernel launch configuration failed");
     HIP_TRY(hipGetLastError());
     lv->inner_pending = false;
   }
   return MGX_OK;
 }
 
+// would mgx_level_sweep(lv, 2, ...) take the two sweeps in one pass (undivided level), and does that pay on a slab?
+extern "C" int mgx_level_pair_pass(mgx_level *lv, int32_t *yes) {
+  if (!lv || !yes) return fail(MGX_EINVAL, "mgx_level_pair_pass: NULL argument");
+  *yes = (lv->elem == 4 ? pair_pass_wanted<float>(lv) : pair_pass_wanted<double>(lv)) ? 1 : 0;
+  return MGX_OK;
+}
+
 extern "C" int mgx_level_sweep_part(mgx_level *lv, int part, int reduce) {
   if (!lv) return fail(MGX_EINVAL, "mgx_level_sweep_part: NULL level");
-  if (part != MGX_PART_EDGE && part != MGX_PART_INNER) return fail(MGX_EINVAL, "mgx_level_sweep_part: part = %d", part);
+  if (part < MGX_PART_EDGE || part > MGX_PART_INNER2) return fail(MGX_EINVAL, "mgx_level_sweep_part: part = %d", part);
   if (!lv->params_set) return fail(MGX_ESTATE, "mgx_level_sweep_part: mgx_level_set_params not called");
   if (!lv->defined) return fail(MGX_ESTATE, "mgx_level_sweep_part: level %d was released", lv->layer);
   TRY(set_device(C(lv)));
@@ -1377,8 +1411,9 @@ extern "C" int mgx_level_download(mgx_level *lv, void *host) {
 
 extern "C" int mgx_level_plane_ptr(mgx_level *lv, int32_t z, int32_t count, void **ptr, size_t *bytes) {
   if (!lv || !ptr || !bytes) return fail(MGX_EINVAL, "mgx_level_plane_ptr: NULL argument");
-  if (count < 1 || z < -1 || z + count - 1 > lv->g.n3 + 2)
-    return fail(MGX_EINVAL, "mgx_level_plane_ptr: planes [%d,%d] outside [-1,%d]", z, z + count - 1, lv->g.n3 + 2);
+  const int extra = lv->lead > 0 ? MGX_SLAB_EXTRA : 0;
+  if (count < 1 || z < -1 - extra || z + count - 1 > lv->g.n3 + 2 + extra)
+    return fail(MGX_EINVAL, "mgx_level_plane_ptr: planes [%d,%d] outside [%d,%d]", z, z + count - 1, -1 - extra, lv->g.n3 + 2 + extra);
   TRY(set_device(C(lv)));
   TRY(materialize(lv));
   // a plane = rows y = 0..n2+1, each from its x = 0 ghost to the end of the pitch

@@ -24,8 +24,8 @@ struct MgxTileList {             // segment sizes, each padded to a multiple of 
 struct MgxFusedPlan {            // per level: tile decomposition and the tile lists (device)
   int ns = 1;                    // sweeps per pass the lists are made for (the reach of a tile grows with it)
   int ty = 0, nw = 4, ZC = 0, ntx = 0, nty = 0, nzc = 0;
-  // [0] every tile; [1] the tiles of the z chunks that hold planes 1, 2, n3-1, n3 (the planes a z slab sends to
-  // its neighbours); [2] the others
+  // [0] every tile; [1] the tiles of the z chunks that hold the outermost planes at either end (two per sweep of the
+  // pass: the planes a z slab sends to its neighbours); [2] the others
   MgxTileList list[3];
   int *d_tiles = nullptr;
   bool valid = false;
@@ -157,7 +157,7 @@ static int mgx_fused_make_plan(MgxFusedPlan &pl, const MgxGeom &g, const std::ve
       const int gi = orders[mgx_fused_order >= 0 && mgx_fused_order < 3 ? mgx_fused_order : 0][go];
       std::vector<Piece> v;
       for (const Piece &q : grp[gi]) {
-        const bool edge = q.z0 <= 2 || q.z1 >= g.n3 - 1;     // holds plane 1, 2, n3-1 or n3
+        const bool edge = q.z0 <= reach || q.z1 >= g.n3 - reach + 1;   // holds one of the `reach` outermost planes at either end
         if (sel == 0 || (sel == 1) == edge) v.push_back(q);
       }
       n_real += (int)v.size();
@@ -200,9 +200,9 @@ int mgx_fused_launch_f64(const MgxFusedPlan &pl, int part, const double *src, do
 int mgx_fused_launch_f32(const MgxFusedPlan &pl, int part, const float *src, float *dst, const MgxGeom &g,
                          const MgxSweepParams<float> &p, const MgxBox *bx, int nb, int reduce, u64 *res, hipStream_t st,
                          const int *stop);
-int mgx_tb2_launch_f64(const MgxFusedPlan &pl, const double *src, double *dst, const MgxGeom &g,
+int mgx_tb2_launch_f64(const MgxFusedPlan &pl, int part, const double *src, double *dst, const MgxGeom &g,
                        const MgxSweepParams<double> &p, const MgxBox *bx, int nb, int reduce, u64 *res, hipStream_t st);
-int mgx_tb2_launch_f32(const MgxFusedPlan &pl, const float *src, float *dst, const MgxGeom &g,
+int mgx_tb2_launch_f32(const MgxFusedPlan &pl, int part, const float *src, float *dst, const MgxGeom &g,
                        const MgxSweepParams<float> &p, const MgxBox *bx, int nb, int reduce, u64 *res, hipStream_t st);
 
 inline int mgx_fused_launch(const MgxFusedPlan &pl, int part, const double *src, double *dst, const MgxGeom &g,
@@ -215,11 +215,11 @@ inline int mgx_fused_launch(const MgxFusedPlan &pl, int part, const float *src, 
                             const int *stop = nullptr) {
   return mgx_fused_launch_f32(pl, part, src, dst, g, p, bx, nb, reduce, res, st, stop);
 }
-inline int mgx_tb2_launch(const MgxFusedPlan &pl, const double *src, double *dst, const MgxGeom &g,
+inline int mgx_tb2_launch(const MgxFusedPlan &pl, int part, const double *src, double *dst, const MgxGeom &g,
                           const MgxSweepParams<double> &p, const MgxBox *bx, int nb, int reduce, u64 *res, hipStream_t st) {
-  return mgx_tb2_launch_f64(pl, src, dst, g, p, bx, nb, reduce, res, st);
+  return mgx_tb2_launch_f64(pl, part, src, dst, g, p, bx, nb, reduce, res, st);
 }
-inline int mgx_tb2_launch(const MgxFusedPlan &pl, const float *src, float *dst, const MgxGeom &g,
+inline int mgx_tb2_launch(const MgxFusedPlan &pl, int part, const float *src, float *dst, const MgxGeom &g,
                           const MgxSweepParams<float> &p, const MgxBox *bx, int nb, int reduce, u64 *res, hipStream_t st) {
-  return mgx_tb2_launch_f32(pl, src, dst, g, p, bx, nb, reduce, res, st);
+  return mgx_tb2_launch_f32(pl, part, src, dst, g, p, bx, nb, reduce, res, st);
 }

@@ -228,7 +228,8 @@ __device__ MGX_TB_BODY_ATTR void mgx_tb_body(const T *__restrict__ src_, T *__re
 
   const long long pzl = g.pz;
   const int k0 = zc0 - L;                        // first step: stage 0 on the lowest plane of the grown chunk
-  const int zmin = -1, zmax = g.n3 + 2;          // planes of the allocation
+  // planes of the allocation: a slab of a decomposed level holds two more on either side (four halo planes)
+  const int zmin = g.n3 != g.n3g ? -3 : -1, zmax = g.n3 != g.n3g ? g.n3 + 4 : g.n3 + 2;
   auto fetch = [&](V2 (&w)[R], int z) __attribute__((always_inline)) {
     z = z < zmin ? zmin : z > zmax ? zmax : z;   // past the allocation: any plane, the data are not used
     const char *pb = reinterpret_cast<const char *>(src + pzl * (z + 1));
@@ -749,7 +750,7 @@ __device__ __attribute__((noinline)) void mgx_tb_prefetch_wave(const T *__restri
   }
   const int k0 = zc0 - L, kend = zc1 + L;
   auto touch = [&](int z) __attribute__((always_inline)) {
-    if (z < -1 || z > g.n3 + 2) return;          // uniform
+    if (z < (g.n3 != g.n3g ? -3 : -1) || z > (g.n3 != g.n3g ? g.n3 + 4 : g.n3 + 2)) return;          // uniform
     const unsigned long long base = (unsigned long long)(src + g.pz * (long long)(z + 1));
     mgx_i4 rs;
     rs.x = (int)(unsigned)(base & 0xffffffffull);
@@ -867,7 +868,7 @@ __global__ __launch_bounds__(MGX_TB_WAVES(NW) * 64) void k_tb_sweep(const T *__r
 }
 
 template <typename T, int NS, int TY, int NW, int DF>
-static int mgx_tb_launch_cfg(const MgxFusedPlan &pl, const T *src, T *dst, const MgxGeom &g, const MgxSweepParams<T> &p,
+static int mgx_tb_launch_cfg(const MgxFusedPlan &pl, int part, const T *src, T *dst, const MgxGeom &g, const MgxSweepParams<T> &p,
                              const MgxBox *bx, int nb, int reduce, u64 *res, hipStream_t st) {
   constexpr size_t lds = mgx_tb_lds_field<T, NS, TY, NW>() + sizeof(MgxBoxLds<T>);
   static bool attr_done[MGX_MAX_DEVICES] = {false};          // the attribute is per device and function: set once per device
@@ -879,10 +880,10 @@ static int mgx_tb_launch_cfg(const MgxFusedPlan &pl, const T *src, T *dst, const
       return -1;
     if (dev >= 0 && dev < MGX_MAX_DEVICES) attr_done[dev] = true;
   }
-  const MgxTileList &tl = pl.list[0];
+  const MgxTileList &tl = pl.list[part];         // 0 every piece; 1 the pieces that hold a slab's outermost planes; 2 the others
   const int total = tl.n_box + tl.n_const + tl.n_fast;
   if (total > 0)
     hipLaunchKernelGGL((k_tb_sweep<T, NS, TY, NW, DF>), dim3((unsigned)total), dim3(MGX_TB_WAVES(NW) * 64), lds, st, src, dst, g, p, bx,
-                       nb, pl.ntx, pl.d_tiles + 3 * tl.offset, (reduce & 3) ? tl.n_real : 0, reduce, res);
+                       nb, pl.ntx, pl.d_tiles + 3 * tl.offset, (reduce & 3) ? pl.list[0].n_real : 0, reduce, res);
   return 0;
 }

@@ -8,7 +8,7 @@ module mgx_c
 
   integer(c_int), parameter :: MGX_BC_PERIODIC = 1, MGX_BC_DIRICHLET = 2, MGX_BC_NEUMANN = 3   ! t_bc.f90:13-15
   integer(c_int), parameter :: MGX_RED_ERR = 1, MGX_RED_SUM = 2
-  integer(c_int), parameter :: MGX_PART_EDGE = 1, MGX_PART_INNER = 2
+  integer(c_int), parameter :: MGX_PART_EDGE = 1, MGX_PART_INNER = 2, MGX_PART_EDGE2 = 3, MGX_PART_INNER2 = 4
   integer(c_int), parameter :: MGX_KERNEL_AUTO = 0, MGX_KERNEL_TWO_PASS = 1, MGX_KERNEL_FUSED = 2, MGX_KERNEL_PAIR = 3, &
        MGX_KERNEL_LEX = 4   ! the reference's own sweep order (slow; results of the reference on one thread)
   integer(c_int), parameter :: MGX_OK = 0, MGX_EINVAL = -1, MGX_EHIP = -2, MGX_ENOMEM = -3, MGX_ESTATE = -4, MGX_ELIMIT = -5
@@ -133,6 +133,12 @@ module mgx_c
        integer(c_int32_t), value :: zlo, zhi
        integer(c_int) :: rc
      end function mgx_level_half_sweep
+     function mgx_level_pair_pass(lv, yes) bind(C, name="mgx_level_pair_pass") result(rc)
+       import :: c_int, c_int32_t, c_ptr
+       type(c_ptr), value :: lv
+       integer(c_int32_t), intent(out) :: yes
+       integer(c_int) :: rc
+     end function mgx_level_pair_pass
      function mgx_level_result_reset(lv) bind(C, name="mgx_level_result_reset") result(rc)
        import :: c_int, c_ptr
        type(c_ptr), value :: lv

@@ -21,6 +21,7 @@ KERNEL_LEX = 4      # the reference's own sweep order (results of the reference 
 INTERP_FULL, INTERP_HALF = 1, 2
 BC_PERIODIC, BC_DIRICHLET, BC_NEUMANN = 1, 2, 3
 PART_EDGE, PART_INNER = 1, 2
+PART_EDGE2, PART_INNER2 = 3, 4        # the two launches of a pass of two sweeps
 
 SYMBOLS = [
     "mgx_last_error", "mgx_version", "mgx_ctx_create", "mgx_ctx_destroy", "mgx_ctx_sync", "mgx_ctx_set_kernel",
@@ -28,7 +29,7 @@ SYMBOLS = [
     "mgx_ctx_capture_begin", "mgx_ctx_capture_end", "mgx_graph_launch", "mgx_graph_destroy",
     "mgx_level_create", "mgx_level_create_slab", "mgx_level_destroy", "mgx_level_bring_back", "mgx_level_release",
     "mgx_level_set_params", "mgx_level_set_boxes", "mgx_level_setup", "mgx_level_sweep", "mgx_level_sweep_part",
-    "mgx_level_half_sweep",
+    "mgx_level_half_sweep", "mgx_level_pair_pass",
     "mgx_level_result_reset", "mgx_level_result", "mgx_level_abs_sum", "mgx_level_abs_sum_limbs",
     "mgx_level_abs_sum_noalloc", "mgx_level_solve",
     "mgx_limbs_to_double", "mgx_level_count_nonconst", "mgx_level_tolerance", "mgx_restrict", "mgx_prolong",
@@ -81,6 +82,7 @@ def load():
         "mgx_level_sweep": [vp, C.c_int, C.c_int],
         "mgx_level_sweep_part": [vp, C.c_int, C.c_int],
         "mgx_level_half_sweep": [vp, C.c_int, i32, i32, C.c_int],
+        "mgx_level_pair_pass": [vp, pi32],
         "mgx_level_result_reset": [vp],
         "mgx_level_result": [vp, pdbl, pdbl, pu64],
         "mgx_level_abs_sum": [vp, pdbl], "mgx_level_abs_sum_limbs": [vp, pu64],
@@ -260,6 +262,12 @@ class DeviceLevel:
 
     def sweep_part(self, part: int, reduce: int = RED_ERR | RED_SUM):
         _ck(self.L.mgx_level_sweep_part(self.h, int(part), int(reduce)))
+
+    def pair_pass(self) -> bool:
+        """does sweep(2) take the two sweeps in one pass (undivided level) / do such passes pay (slab)?"""
+        yes = C.c_int32()
+        _ck(self.L.mgx_level_pair_pass(self.h, C.byref(yes)))
+        return bool(yes.value)
 
     def half_sweep(self, parity: int, zlo: int, zhi: int, reduce: int = 0):
         _ck(self.L.mgx_level_half_sweep(self.h, int(parity), int(zlo), int(zhi), int(reduce)))

@@ -117,6 +117,21 @@ class SlabLevel:
         self.periodic_z = top.bc6()[4] == lib.BC_PERIODIC or top.bc6()[5] == lib.BC_PERIODIC
         self.reduce = lib.RED_ERR | lib.RED_SUM
         self.overlap = overlap and hasattr(self.lv, "sweep_part")
+        self.depth = 2
+
+    def choose_depth(self, allow_pairs: bool = True):
+        """halo planes per side: 2 (one sweep per exchange), or 4 where the library takes two sweeps in one pass over
+        the slab (gs_V's legs: half as many exchanges and passes).  Every rank must exchange the same number of
+        planes: the ranks agree (a slab thinner than four planes anywhere, or a rank whose library says no: 2)."""
+        ask = getattr(self.lv, "pair_pass", None)
+        yes = 1 if (allow_pairs and ask is not None and self.n3 >= 4 and ask()) else 0
+        if self.world > 1:
+            import torch
+            t = torch.tensor([yes], dtype=torch.int64, device=self._scalar_device())
+            self.dist.all_reduce(t, op=self.dist.ReduceOp.MIN, group=self.group)
+            yes = int(t.item())
+        self.depth = 4 if yes else 2
+        return self.depth
 
     # ---- communication -------------------------------------------------------------------------
     def planes(self, z: int, count: int):
@@ -165,7 +180,8 @@ class SlabLevel:
             w.wait()
 
     def exchange_halos(self):
-        """new planes 1,2 -> lower neighbour's n3+1,n3+2; new planes n3-1,n3 -> upper neighbour's -1,0"""
+        """new planes 1..d -> lower neighbour's n3+1..n3+d; new planes n3-d+1..n3 -> upper neighbour's 1-d..0
+        (d = self.depth: 2, or 4 where two sweeps are taken per pass)"""
         for w in self._start_exchange():
             w.wait()
 
@@ -173,13 +189,14 @@ class SlabLevel:
         if self.world == 1:
             return []
         spec = []
+        d = self.depth
         # every rank lists its transfers lower-neighbour first: matching order on both sides of a link
         if self.lower is not None:
-            spec.append((True, self.planes(1, 2), self.lower))
-            spec.append((False, self.planes(-1, 2), self.lower))
+            spec.append((True, self.planes(1, d), self.lower))
+            spec.append((False, self.planes(1 - d, d), self.lower))
         if self.upper is not None:
-            spec.append((False, self.planes(self.n3 + 1, 2), self.upper))
-            spec.append((True, self.planes(self.n3 - 1, 2), self.upper))
+            spec.append((False, self.planes(self.n3 + 1, d), self.upper))
+            spec.append((True, self.planes(self.n3 - d + 1, d), self.upper))
         return self._post(spec)
 
     def _exchange_periodic_ghosts(self):
@@ -226,6 +243,22 @@ class SlabLevel:
         self.lv.sweep_part(lib.PART_EDGE, red)
         works = self._start_exchange()
         self.lv.sweep_part(lib.PART_INNER, red)
+        for w in works:
+            w.wait()
+
+    def sweep_pair(self, reduce: Optional[int] = None):
+        """two red-black sweeps in one pass over the slab and ONE exchange (of four planes): the form gs_V's legs
+        take (m_gs_CDS.F90:240-242, 271-273).  Needs self.depth == 4.  Reductions are those of the second sweep."""
+        if self.depth != 4:
+            raise RuntimeError("sweep_pair needs four halo planes (choose_depth)")
+        red = self.reduce if reduce is None else reduce
+        if self.world == 1 or not self.overlap:
+            self.lv.sweep(2, red)
+            self.exchange_halos()
+            return
+        self.lv.sweep_part(lib.PART_EDGE2, red)
+        works = self._start_exchange()
+        self.lv.sweep_part(lib.PART_INNER2, red)
         for w in works:
             w.wait()
 
@@ -290,6 +323,8 @@ class SlabDevice(SlabLevel):
         self.periodic_z = False
         self.reduce = lib.RED_ERR | lib.RED_SUM
         self.overlap = overlap and hasattr(self.lv, "sweep_part")
+        self.depth = 2
+        self.allow_pairs = True
 
     # parameters come through cycle.Solver.push_params
     def set_params(self, sor, a, bc):
@@ -298,6 +333,7 @@ class SlabDevice(SlabLevel):
 
     def set_boxes(self, *table):
         self.lv.set_boxes(*table)
+        self.choose_depth(self.allow_pairs)      # (the library's answer depends on the box table: at most 32 boxes)
 
     def bring_back(self):
         self.lv.bring_back()
@@ -324,8 +360,13 @@ class SlabDevice(SlabLevel):
 
     def sweep(self, nsweeps: int = 1, reduce: Optional[int] = None):     # `nsweeps` x gs_step
         red = self.reduce if reduce is None else reduce
-        for s in range(int(nsweeps)):
+        s, nsweeps = 0, int(nsweeps)
+        while self.depth == 4 and s + 2 <= nsweeps:                     # pairs of sweeps in one pass and one exchange
+            SlabLevel.sweep_pair(self, red if s + 2 == nsweeps else 0)
+            s += 2
+        while s < nsweeps:
             SlabLevel.sweep(self, red if s == nsweeps - 1 else 0)
+            s += 1
 
     def abs_sum(self) -> float:
         """grid_sum over the whole level: the slabs' exact integer sums added exactly"""
@@ -398,7 +439,7 @@ class SlabSolver:
 
     @staticmethod
     def build(top: G.MgGrid, ctx, rank: int, world: int, group=None, level_factory=None, plane_tensor=None,
-              transfer=None, overlap: bool = True, replicate_below: int = 16, **kw):
+              transfer=None, overlap: bool = True, replicate_below: int = 16, pairs: bool = True, **kw):
         import torch.distributed as dist
         from . import cycle
         levels = list(top.levels())
@@ -423,8 +464,10 @@ class SlabSolver:
 
         def slab_of(g):
             z0, n3 = by_layer[g.layer]
-            return SlabDevice(ctx, g, rank, world, z0, n3, group=group, level_factory=level_factory,
-                              plane_tensor=plane_tensor, overlap=overlap)
+            d = SlabDevice(ctx, g, rank, world, z0, n3, group=group, level_factory=level_factory,
+                           plane_tensor=plane_tensor, overlap=overlap)
+            d.allow_pairs = pairs                # two sweeps per pass and exchange where the library offers them
+            return d
 
         class _Solver(cycle.Solver):
             edge = None                          # the slab of the first replicated level's geometry

@@ -41,6 +41,7 @@ def main():
         h = s.history_array()
         np.savez(out, planes=planes, per=np.array([g.itt for g in top.levels()]),
                  kinds=np.array([type(g.dev).__name__ for g in top.levels()]),
+                 depths=np.array([getattr(g.dev, "depth", 0) for g in top.levels()]),
                  **{f"h_{k}": h[k] for k in ("layer", "kind", "itt", "tol", "sum", "err")})
     dist.barrier()
     s.close()

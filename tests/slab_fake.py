@@ -7,15 +7,23 @@ import torch
 from oracle import oracle as orc
 
 
+OFF = 3      # V[lz + OFF] = local plane lz; local planes -3 .. n3+4 exist (four halo planes per side, like a device slab)
+
+
 class FakeSlabLevel:
+    pairs = False        # answer of pair_pass(): set True to have the slab layer take two sweeps per exchange
+
     def __init__(self, layer, n, dtype, z0, n3_local, global_init=None):
         self.n_global = tuple(int(v) for v in n)
         self.dtype = np.dtype(dtype)
         self.z0, self.n3 = int(z0), int(n3_local)
         n1, n2, _ = self.n_global
-        self.V = np.zeros((self.n3 + 4, n2 + 2, n1 + 2), dtype=self.dtype)     # local planes -1 .. n3+2
+        self.V = np.zeros((self.n3 + 8, n2 + 2, n1 + 2), dtype=self.dtype)     # local planes -3 .. n3+4
         self.global_init = global_init
         self.res = (0.0, 0.0, 0)
+
+    def pair_pass(self):
+        return bool(self.pairs)
 
     def set_params(self, sor, a, bc):
         self.sor, self.a, self.bc = float(sor), tuple(a), tuple(bc)
@@ -27,13 +35,13 @@ class FakeSlabLevel:
     def _global_level(self):
         return orc.Level(n=self.n_global, bc=self.bc, sor=self.sor, a=self.a, boxes=self.boxes)
 
-    def _pseudo_level(self):
-        """local planes 0 .. n3+1 as the interior of a level of depth n3+2 (boxes shifted in z)"""
-        sh = 1 - self.z0
+    def _pseudo_level(self, grow):
+        """local planes 1-grow .. n3+grow as the interior of a level of depth n3 + 2 grow (boxes shifted in z)"""
+        sh = grow - self.z0
         bx = [orc.Box(tuple(b.place[:4]) + (b.place[4] + sh, b.place[5] + sh) if any(b.place) else b.place, b.val, b.rho,
                       b.constant) for b in self.boxes]
         n1, n2, _ = self.n_global
-        return orc.Level(n=(n1, n2, self.n3 + 2), bc=self.bc, sor=self.sor, a=self.a, boxes=bx)
+        return orc.Level(n=(n1, n2, self.n3 + 2 * grow), bc=self.bc, sor=self.sor, a=self.a, boxes=bx)
 
     def setup(self, init):
         G = self._global_level()
@@ -50,50 +58,66 @@ class FakeSlabLevel:
             inner_halo = (lz <= 0 and self.z0 > 0) or (lz >= self.n3 + 1 and self.z0 + self.n3 < n3g)
             periodic_ghost = ((gz == 0 and self.bc[4] == 1) or (gz == n3g + 1 and self.bc[5] == 1)) and not whole
             if 0 <= gz <= n3g + 1 and not inner_halo and not periodic_ghost:    # the rest is the exchange's job
-                self.V[lz + 1] = Vg[gz]
+                self.V[lz + OFF] = Vg[gz]
 
     def halo_written(self):
         pass
 
-    def sweep(self, nsweeps, reduce):
-        assert nsweeps == 1
+    def _half_sweeps(self, count, reduce):
+        """`count` colour half-sweeps (black first) over the slab grown by what the later ones still need, as the
+        device kernels do: half-sweep s of `count` updates local planes 1-(count-1-s) .. n3+(count-1-s) (never a global
+        ghost plane); what it computes beyond is never read by a plane that counts.  Halo planes are put back at the
+        end; the reductions are those of the last full sweep over the slab's own planes."""
         n3 = self.n3
-        keep = {lz: self.V[lz + 1].copy() for lz in (-1, 0, n3 + 1, n3 + 2)}
-        old = self.V[2:n3 + 2, 1:-1, 1:-1].copy()
-        P = self._pseudo_level()
-        flip = (self.z0 + 1) & 1
-        orc.half_sweep(P, self.V, 1 ^ flip)          # black = odd x + y + z (global)
-        # black never runs on a global ghost plane: undo it there before red looks at it
-        if self.z0 == 0:
-            self.V[1] = keep[0]
-        if self.z0 + n3 == self.n_global[2]:
-            self.V[n3 + 2] = keep[n3 + 1]
-        orc.half_sweep(P, self.V, 0 ^ flip)
+        grow = count - 1                                    # planes the first half-sweep reaches beyond the slab
+        view = self.V[OFF - grow:OFF + n3 + grow + 2]          # planes -grow .. n3+grow+1: the pseudo level with its z ghosts
+        halo = [lz for lz in range(-3, n3 + 5) if lz < 1 or lz > n3]
+        keep = {lz: self.V[lz + OFF].copy() for lz in halo}
+        P = self._pseudo_level(grow)
+        flip = (grow - self.z0) & 1                          # parity of pseudo z against global z
+        n3g = self.n_global[2]
+        old = None
+        for s in range(count):
+            if s == count - 2:
+                old = self.V[OFF + 1:OFF + n3 + 1, 1:-1, 1:-1].copy()
+            colour = 1 if s % 2 == 0 else 0                  # black = odd x + y + z (global) first
+            orc.half_sweep(P, view, colour ^ flip)
+            # a half-sweep never runs on a global ghost plane (or beyond): undo it there before the next one looks
+            for lz in halo:
+                gz = lz + self.z0
+                if gz < 1 or gz > n3g:
+                    self.V[lz + OFF] = keep[lz]
         for lz, v in keep.items():
-            self.V[lz + 1] = v
-        new = self.V[2:n3 + 2, 1:-1, 1:-1]
+            self.V[lz + OFF] = v
+        new = self.V[OFF + 1:OFF + n3 + 1, 1:-1, 1:-1]
         d = new - old
         e2 = float((d * d).max()) if (reduce & 1) else 0.0
-        s, units = (0.0, 0)
+        s_, units = (0.0, 0)
         if reduce & 2:
             n1, n2, _ = self.n_global
-            s, units = orc.abs_sum_exact(orc.Level(n=(n1, n2, n3)), np.ascontiguousarray(self.V[1:n3 + 3]))
-        self.res = (e2, s, units)
+            s_, units = orc.abs_sum_exact(orc.Level(n=(n1, n2, n3)), np.ascontiguousarray(self.V[OFF:OFF + n3 + 2]))
+        self.res = (e2, s_, units)
+
+    def sweep(self, nsweeps, reduce):
+        assert nsweeps in (1, 2)
+        self._half_sweeps(2 * int(nsweeps), reduce)
 
     def sweep_part(self, part, reduce):
-        """edge part = the whole sweep (the new boundary planes exist afterwards); inner part = nothing left to do"""
+        """edge part = the whole pass (the new boundary planes exist afterwards); inner part = nothing left to do"""
         if part == 1:
             self.sweep(1, reduce)
+        elif part == 3:
+            self.sweep(2, reduce)
 
     def result(self):
         return self.res
 
     def download(self):
-        return self.V[1:self.n3 + 3].copy()
+        return self.V[OFF:OFF + self.n3 + 2].copy()
 
 
 def plane_tensor(lv: FakeSlabLevel, z: int, count: int):
-    return torch.from_numpy(lv.V[z + 1:z + 1 + count])
+    return torch.from_numpy(lv.V[z + OFF:z + OFF + count])
 
 
 class FakeCycleLevel(FakeSlabLevel):
@@ -116,14 +140,14 @@ class FakeCycleLevel(FakeSlabLevel):
 
     def abs_sum_limbs(self):
         n1, n2, _ = self.n_global
-        return orc.abs_sum_exact(orc.Level(n=(n1, n2, self.n3)), np.ascontiguousarray(self.V[1:self.n3 + 3]))[1]
+        return orc.abs_sum_exact(orc.Level(n=(n1, n2, self.n3)), np.ascontiguousarray(self.V[OFF:OFF + self.n3 + 2]))[1]
 
     def gather_global(self):
         """the undivided level as every rank sees it: owned planes of all ranks + the two global ghost planes"""
         import torch.distributed as dist
         n1, n2, n3g = self.n_global
         parts = [None] * dist.get_world_size()
-        dist.all_gather_object(parts, (self.z0, self.n3, self.V[1:self.n3 + 3].copy()))
+        dist.all_gather_object(parts, (self.z0, self.n3, self.V[OFF:OFF + self.n3 + 2].copy()))
         Vg = np.zeros((n3g + 2, n2 + 2, n1 + 2), dtype=self.dtype)
         for z0, n3, pl in parts:
             Vg[z0 + 1:z0 + n3 + 1] = pl[1:-1]
@@ -142,7 +166,7 @@ class FakeCycleLevel(FakeSlabLevel):
             inner_halo = (lz == 0 and self.z0 > 0) or (lz == self.n3 + 1 and self.z0 + self.n3 < n3g)
             periodic_ghost = ((gz == 0 and self.bc[4] == 1) or (gz == n3g + 1 and self.bc[5] == 1)) and not whole
             if not inner_halo and not periodic_ghost:
-                self.V[lz + 1] = Vg[gz]
+                self.V[lz + OFF] = Vg[gz]
 
     def setup(self, init):
         Vg = self.gather_global()
@@ -150,7 +174,11 @@ class FakeCycleLevel(FakeSlabLevel):
         self.take_from_global(Vg)
 
     def sweep(self, nsweeps, reduce):
-        for _ in range(int(nsweeps)):
+        nsweeps = int(nsweeps)
+        if nsweeps == 2 and self.pairs:
+            FakeSlabLevel.sweep(self, 2, reduce)
+            return
+        for _ in range(nsweeps):
             FakeSlabLevel.sweep(self, 1, reduce)
 
 

@@ -33,8 +33,19 @@ def _free_port():
     return p
 
 
+# V cycles with two sweeps per pass and ONE exchange of four planes a side on every slab level (MGX_PAIR_PASS=1 makes the
+# library offer them at these sizes; by itself it does so from 12 million cells a slab on)
+PAIR_CASES = [("solve_64x48x80_v_half", "f32", None, 4), ("solve_80_v", "f64", ("sor 1.8", "sor 1.6"), 4),
+              ("config4", "f64", None, 4), ("solve_80_v", "f64", ("sor 1.8", "sor 1.6"), 12)]
+
+
+@pytest.mark.parametrize("name,prec,sub,below", PAIR_CASES)
+def test_two_rank_solve_with_pair_passes_matches_oracle(name, prec, sub, below, tmp_path):
+    test_two_rank_solve_matches_oracle(name, prec, sub, below, tmp_path, pairs=True)
+
+
 @pytest.mark.parametrize("name,prec,sub,below", CASES)
-def test_two_rank_solve_matches_oracle(name, prec, sub, below, tmp_path):
+def test_two_rank_solve_matches_oracle(name, prec, sub, below, tmp_path, pairs=False):
     text = config4_input() if name == "config4" else str(load(f"{name}_{prec}")["input"])
     if sub:
         assert sub[0] in text
@@ -46,12 +57,15 @@ def test_two_rank_solve_matches_oracle(name, prec, sub, below, tmp_path):
     case, out = str(tmp_path / "case.npz"), str(tmp_path / "out.npz")
     np.savez(case, input=text, dtype=np.dtype(DT[prec]).name)
     env = dict(os.environ, PYTHONPATH=ROOT)
+    if pairs:
+        env["MGX_PAIR_PASS"] = "1"
     r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2",
                         "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
                         os.path.join(ROOT, "tests", "dist_solve_worker.py"), case, out, "gloo", str(below)],
                        env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, universal_newlines=True, timeout=150)
     assert r.returncode == 0, r.stdout[-3000:]
     d = np.load(out)
+    assert (4 in list(d["depths"])) == pairs and (int(d["depths"][0]) == 4) == pairs
     if below > 4:
         assert "ReplicatedDevice" in list(d["kinds"]) and str(d["kinds"][0]) == "SlabDevice"
     assert [int(v) for v in d["per"]] == per

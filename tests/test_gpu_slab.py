@@ -87,6 +87,82 @@ def test_slab_sweeps_equal_undivided(dtype, parts, two_launches):
     ctx.close()
 
 
+# two sweeps in one pass on every slab: four halo planes per side, copied once per pass
+@pytest.mark.parametrize("two_launches", [False, True])
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("parts", [[(0, 13), (13, 11)], [(0, 8), (8, 7), (15, 9)], [(0, 135), (135, 105)],
+                                   [(0, 41), (41, 64), (105, 35)]])
+def test_slab_pair_passes_equal_undivided(dtype, parts, two_launches):
+    import torch
+    from multigrid_amd import lib, slab
+    from oracle import oracle as orc
+    n = (150, 45, sum(k for _, k in parts))
+    bc = (1, 1, 1, 1, 3, 2)
+    place = np.array([[40, 110, 10, 30, 1, 2], [40, 110, 10, 30, n[2] - 1, n[2]], [60, 90, 15, 25, 3, n[2] - 2]], dtype=np.int32)
+    boxes = (place, [0.5, -0.5, 0.0], [1.0, 1.0, 3.0], [1, 1, 0])
+    ctx = lib.Context(0, None)
+    pair_ctx = lib.Context(0, None)
+    pair_ctx.set_kernel(lib.KERNEL_PAIR)           # the undivided level takes the pair pass at this size too
+    whole = _levels(pair_ctx, n, dtype, [(0, n[2])], bc, boxes)[0]
+    slabs = _levels(ctx, n, dtype, parts, bc, boxes)
+    rng = np.random.default_rng(8)
+    V0 = rng.standard_normal((n[2] + 2, n[1] + 2, n[0] + 2)).astype(dtype)
+    whole.upload(V0)
+    whole.setup(False)
+    L = orc.Level(n=n, bc=bc, sor=1.6, a=(0.3, 0.3, 0.4),
+                  boxes=[orc.Box(tuple(int(v) for v in p), v_, r_, bool(c_)) for p, v_, r_, c_ in zip(place, *boxes[1:])])
+    Vref = V0.copy()
+    orc.setup(L, Vref, False)
+
+    def exchange():
+        ctx.sync()
+        for lo, up in zip(slabs[:-1], slabs[1:]):
+            slab.device_plane_tensor(up, -3, 4).copy_(slab.device_plane_tensor(lo, lo.n3_local - 3, 4))
+            slab.device_plane_tensor(lo, lo.n3_local + 1, 4).copy_(slab.device_plane_tensor(up, 1, 4))
+        torch.cuda.synchronize()
+
+    for lv, (z0, k) in zip(slabs, parts):
+        lv.upload(np.ascontiguousarray(V0[z0:z0 + k + 2]))
+        lv.setup(False)
+    exchange()
+    for lv in slabs:
+        lv.halo_written()
+    for it in range(3):
+        orc.sweep(L, Vref, orc.ORDER_RB)
+        e_ref = orc.sweep(L, Vref, orc.ORDER_RB)
+        s_ref, u_ref = orc.abs_sum_exact(L, Vref)
+        whole.sweep(2, 3)
+        e_w, s_w, u_w = whole.result()
+        assert (e_w, u_w) == (e_ref, u_ref)
+        if two_launches:     # tiles at the slab's ends first, the four planes a side copied, then the rest
+            for lv in slabs:
+                lv.sweep_part(lib.PART_EDGE2, 3)
+            exchange()
+            for lv in slabs:
+                lv.sweep_part(lib.PART_INNER2, 3)
+        else:
+            for lv in slabs:
+                lv.sweep(2, 3)
+            exchange()
+        res = [lv.result() for lv in slabs]
+        assert max(r[0] for r in res) == e_ref
+        assert sum(r[2] for r in res) == u_ref
+        for lv, (z0, k) in zip(slabs, parts):
+            got = lv.download()
+            assert np.array_equal(got.view(np.uint8), Vref[z0:z0 + k + 2].view(np.uint8)), f"pass {it} slab z0={z0}"
+        # a single sweep in between (odd counts, grid_solve's loop) goes on from the same four planes
+        e_ref = orc.sweep(L, Vref, orc.ORDER_RB)
+        whole.sweep(1, 1)
+        for lv in slabs:
+            lv.sweep(1, 1)
+        exchange()
+        assert max(lv.result()[0] for lv in slabs) == e_ref == whole.result()[0]
+    for lv, (z0, k) in zip(slabs, parts):
+        assert np.array_equal(lv.download().view(np.uint8), Vref[z0:z0 + k + 2].view(np.uint8))
+    ctx.close()
+    pair_ctx.close()
+
+
 def test_slab_two_pass_kernel_refused():
     from multigrid_amd import lib
     ctx = lib.Context(0, None)

@@ -103,7 +103,7 @@ def _read(case):
     return mgio.iomg_read(IO, dtype=case["dtype"]), mgio.read_method(IO)
 
 
-def _worker(rank, world, port, name, outdir, replicate_below=4):
+def _worker(rank, world, port, name, outdir, replicate_below=4, pairs=False):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     dist.init_process_group("gloo", rank=rank, world_size=world)
@@ -115,18 +115,26 @@ def _worker(rank, world, port, name, outdir, replicate_below=4):
         case = CASES[name]
         top, method = _read(case)
         V, hist, per = orc.solve(oracle_levels(top), method, case["dtype"], order=orc.ORDER_RB, sum_mode=orc.SUM_EXACT)
+        keep = hist
+        extra = {}
+        if pairs:                 # the levels offer two sweeps per pass: legs of a cycle run as passes with ONE exchange
+            slab_fake.FakeSlabLevel.pairs = True
+            extra = dict(print_sums=False)         # (with the print-only sums every sweep of a leg is a call of its own)
+            keep = hist[hist["kind"] != 1]
         s = slab.SlabSolver.build(top, None, rank, world, level_factory=slab_fake.FakeCycleLevel,
                                   plane_tensor=slab_fake.plane_tensor,
                                   transfer=(slab_fake.fake_restrict, slab_fake.fake_prolong),
-                                  replicate_below=replicate_below)
+                                  replicate_below=replicate_below, **extra)
         kinds = [type(g.dev).__name__ for g in top.levels()]
         open(os.path.join(outdir, f"kinds{rank}"), "w").write(",".join(kinds))
+        depths = [getattr(g.dev, "depth", 0) for g in top.levels()]
+        open(os.path.join(outdir, f"depths{rank}"), "w").write(",".join(map(str, depths)))
         s.mg_gs_cds(method)
         h = s.history_array()
         assert [g.itt for g in top.levels()] == per, ([g.itt for g in top.levels()], per)
-        assert len(h) == len(hist)
+        assert len(h) == len(keep)
         for f in ("layer", "kind", "itt", "tol", "sum", "err"):
-            assert np.array_equal(h[f], hist[f]), f
+            assert np.array_equal(h[f], keep[f]), f
         d = top.dev
         mine = d.download()
         assert np.array_equal(mine[1:-1].view(np.uint8), V[d.z0 + 1:d.z0 + d.n3 + 1].view(np.uint8))
@@ -154,6 +162,17 @@ def test_slab_cycle_with_replicated_coarse_levels(name, world, below, kinds, tmp
     mp.spawn(_worker, args=(world, _free_port(), name, str(tmp_path), below), nprocs=world, join=True)
     assert all((tmp_path / f"ok{r}").exists() for r in range(world))
     assert (tmp_path / "kinds0").read_text() == kinds
+
+
+@pytest.mark.parametrize("name,world,below", [("v_cycle_periodic_z_half", 2, 4), ("v_cycle_periodic_z_half", 3, 20),
+                                              ("bottom_up_mixed", 2, 4)])
+def test_slab_cycle_with_two_sweeps_per_exchange(name, world, below, tmp_path):
+    """levels that offer passes of two sweeps (four halo planes, one exchange per pass): the legs of a V cycle take
+    them, single sweeps (grid_solve's loop, odd counts) go on with four-plane exchanges; same history, counts and
+    potential as the undivided solve"""
+    mp.spawn(_worker, args=(world, _free_port(), name, str(tmp_path), below, True), nprocs=world, join=True)
+    assert all((tmp_path / f"ok{r}").exists() for r in range(world))
+    assert "4" in (tmp_path / "depths0").read_text()
 
 
 def test_aligned_splits():
