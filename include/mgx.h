@@ -152,7 +152,9 @@ int mgx_level_pair_pass(mgx_level *lv, int32_t *yes);
  * receive into -1, 0 and n3+1, n3+2); MGX_PART_INNER sweeps the remaining planes from the same old field and may
  * run while the planes travel.  Every call of the first kind must be followed by one of the second before any
  * other operation on the level.  `reduce` as in mgx_level_sweep, the same value in both calls.  MGX_PART_EDGE2 /
- * MGX_PART_INNER2 are the two launches of a pass of two sweeps (planes 1..4 and n3-3..n3 lie in the first).  No
+ * MGX_PART_INNER2 are the two launches of a pass of two sweeps (planes 1..4 and n3-3..n3 lie in the first).  A host
+ * that keeps four halo planes current and takes a single sweep in between (an odd count) must not send four planes
+ * after MGX_PART_EDGE, which completes two a side: it exchanges after the whole sweep (mgx_level_sweep).  No
  * counterpart in the reference (its sweep runs in one address space). */
 int mgx_level_sweep_part(mgx_level *lv, int part, int reduce);
 /* one colour only (parity 1 = odd x+y+z, 0 = even), planes [zlo,zhi] (local, 1-based,
@@ -174,6 +176,15 @@ int mgx_level_result_reset(mgx_level *lv);
  * of m_gs_CDS.F90:313), abs_sum as mgx_level_abs_sum.  Either pointer may be NULL.
  * sum_limbs (may be NULL) receives the exact integer sum, see mgx_level_abs_sum_limbs. */
 int mgx_level_result(mgx_level *lv, double *err_sq_max, double *abs_sum, uint64_t sum_limbs[2]);
+/* The same record left in device memory, for reductions over several GPUs that never visit the host (libmgx_rccl.so
+ * all-reduces it; replaces the OpenMP reductions of m_gs_CDS.F90:318 and t_mg.f90:803 across devices).  Enqueues what
+ * completes the record behind the sweep and returns at once; the eight 64-bit words belong to the level and hold, once
+ * the stream has got there and until the level is swept or summed again:
+ *   [0] max (vv-V)^2 as the bits of a double (never negative, so unsigned integer order is its order),
+ *   [1..4] the exact sum in base 2^32, least significant first; a digit is the sum of one 32-bit number per thread of
+ *          the sweep, far below 2^56, so the digits of up to 256 records add as plain 64-bit integers,
+ *   [5] nonzero if a value was outside the exact range of the sum, [6] nonzero if a sweep gave up (the field is void). */
+int mgx_level_result_device(mgx_level *lv, const uint64_t **record);
 
 /* grid_sum (t_mg.f90:794-814), call sites m_gs_CDS.F90:136,149,195,206,238,245,269,275.
  * Defined order-independently: sum of rne(|V|*2^72) (nearest-even) as a 128-bit integer,

@@ -6,7 +6,10 @@
  * The reference runs its sweep in one address space under OpenMP (src/m_gs_CDS.F90:318-343); its sketch of a
  * decomposed red-black sweep (src/m_gs_br.F90:47-63) names the exchange of boundary values between the two colour
  * half-sweeps.  Here a sweep of a slab is one fused launch that needs two halo planes per side (mgx_level_sweep on a
- * slab level, mgx.h), so one exchange per sweep replaces that step.
+ * slab level, mgx.h), so one exchange per sweep replaces that step; a pass of two sweeps needs four and one exchange.
+ *
+ * Tested on one GPU only (a communicator of one rank; several slabs of one card exchanged by plain copies): the
+ * machines this library was developed on have a single card, so transfers between ranks have not been run yet.
  *
  * Two ways to run, as in RCCL itself:
  *  - one process (or thread) per GPU: rank 0 calls mgx_comm_unique_id, the host distributes the 128 bytes by its own
@@ -38,11 +41,13 @@ int mgx_comm_create_all(int n, mgx_ctx *const *ctxs, mgx_comm **out /* [n] */);
 int mgx_comm_destroy(mgx_comm *comm);
 
 /* After a sweep (or the edge part of a split sweep, mgx_level_sweep_part) of slab `lv` — the slab of rank r holds the
- * planes between those of ranks r-1 and r+1: the new planes 1, 2 go to rank r-1's n3+1, n3+2 and the new planes
- * n3-1, n3 to rank r+1's -1, 0; the first and the last rank have one neighbour.  No other call is needed before the
- * next sweep.  Replaces the boundary exchange of m_gs_br.F90:55-58. */
-int mgx_slab_exchange(mgx_level *lv, mgx_comm *comm);
-int mgx_slab_exchange_all(int n, mgx_level *const *lvs, mgx_comm *const *comms);
+ * planes between those of ranks r-1 and r+1: with planes = 2 the new planes 1, 2 go to rank r-1's n3+1, n3+2 and the
+ * new planes n3-1, n3 to rank r+1's -1, 0; the first and the last rank have one neighbour.  No other call is needed
+ * before the next sweep.  planes = 4 moves 1..4 to n3+1..n3+4 and n3-3..n3 to -3..0: what a pass of two sweeps reads
+ * (mgx_level_sweep(lv, 2, ..) or MGX_PART_EDGE2/INNER2 where mgx_level_pair_pass says yes); single sweeps may follow
+ * such an exchange as well.  Replaces the boundary exchange of m_gs_br.F90:55-58. */
+int mgx_slab_exchange(mgx_level *lv, mgx_comm *comm, int planes);
+int mgx_slab_exchange_all(int n, mgx_level *const *lvs, mgx_comm *const *comms, int planes);
 /* After grid_setup of a level with a periodic C direction (t_mg.f90:553-583): ghost plane 0 of the first rank is plane
  * n3 of the last (c0_periodic), ghost plane n3+1 of the last rank is plane 1 of the first (c1_periodic).  Call it
  * before the first mgx_slab_exchange after a set-up, restriction or prolongation, then mgx_level_halo_written. */
@@ -51,8 +56,9 @@ int mgx_slab_periodic_ghosts_all(int n, mgx_level *const *lvs, mgx_comm *const *
 
 /* [sync] mgx_level_result over the whole level: max of err_sq_max, and the exact integer sum of the slabs' sums (the
  * 128-bit integers are added as four 32-bit digits in 64-bit words, so every rank gets the same bits and the result
- * does not depend on the number of slabs); abs_sum is NaN on every rank if any slab held |V| >= 2^20.  Replaces the
- * OpenMP reductions of grid_sum (t_mg.f90:803) and gs (m_gs_CDS.F90:318). */
+ * does not depend on the number of slabs); abs_sum is NaN on every rank if any slab held |V| >= 2^20.  The slabs'
+ * records are reduced where the sweeps left them on the devices (mgx_level_result_device): the host waits once, for
+ * the reduced record.  Replaces the OpenMP reductions of grid_sum (t_mg.f90:803) and gs (m_gs_CDS.F90:318). */
 int mgx_allreduce_result(mgx_level *lv, mgx_comm *comm, double *err_sq_max, double *abs_sum, uint64_t sum_limbs[2]);
 int mgx_allreduce_result_all(int n, mgx_level *const *lvs, mgx_comm *const *comms, double *err_sq_max, double *abs_sum,
                              uint64_t sum_limbs[2]);

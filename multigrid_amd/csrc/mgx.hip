@@ -1049,6 +1049,21 @@ static int fetch_result(mgx_level *lv, double *err, double *sum, uint64_t limbs_
   return MGX_OK;
 }
 
+// the folded record of the level's last sweep, left on the device: for reductions over several GPUs that never visit the
+// host (libmgx_rccl.so all-reduces it in place)
+extern "C" int mgx_level_result_device(mgx_level *lv, const uint64_t **record) {
+  if (!lv || !record) return fail(MGX_EINVAL, "mgx_level_result_device: NULL argument");
+  mgx_ctx *c = C(lv);
+  TRY(set_device(c));
+  if (lv->slots_dirty) {
+    hipLaunchKernelGGL(k_fold_result, dim3(1), dim3(MGX_RES_SLOTS), 0, c->stream, lv->d_res);
+    HIP_TRY(hipGetLastError());
+    lv->slots_dirty = false;
+  }
+  *record = (const uint64_t *)lv->d_res;
+  return MGX_OK;
+}
+
 extern "C" int mgx_level_result(mgx_level *lv, double *err_sq_max, double *abs_sum, uint64_t sum_limbs[2]) {
   if (!lv) return fail(MGX_EINVAL, "mgx_level_result: NULL level");
   NOT_WHILE_CAPTURING(C(lv), "mgx_level_result");

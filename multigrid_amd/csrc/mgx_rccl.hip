@@ -38,9 +38,10 @@ static int cfail(int code, const char *fmt, ...) {
     if (r_ != MGX_OK) return cfail(r_, "%s: %s", #expr, mgx_last_error());                    \
   } while (0)
 
-// words of the all-reduced record: four 32-bit digits of the integer sum in 64-bit words (SUM), then max dV^2 and the
-// "a slab could not sum exactly" flag as doubles (MAX)
-enum { W_DIGITS = 0, W_MAX = 4, W_WORDS = 6 };
+// A level's result record (mgx_level_result_device) is all-reduced from where the sweep left it on the device: words
+// 1..4 (digits of the integer sum) with SUM, words 0..6 with MAX for max dV^2 (bits of a double that is never negative:
+// unsigned order is its order) and the two flags.  Words of the reduced copy:
+enum { W_MAX = 0, W_E2 = 0, W_BAD = 5, W_GAVE_UP = 6, W_NMAX = 7, W_DIGITS = 8, W_WORDS = 12 };
 
 struct mgx_comm {
   ncclComm_t nccl = nullptr;
@@ -157,22 +158,24 @@ static int plane(mgx_level *lv, int z, int count, Plane *p) {
 
 // the transfers of one rank; to be called between ncclGroupStart and ncclGroupEnd.  Both sides of a link list the
 // transfers over it in the same order.
-static int post_halo(mgx_level *lv, mgx_comm *c) {
+static int post_halo(mgx_level *lv, mgx_comm *c, int d) {
   int32_t n3 = 0;
   int r = check_pair("mgx_slab_exchange", lv, c, &n3);
   if (r != MGX_OK) return r;
+  if (d != 2 && d != 4) return cfail(MGX_EINVAL, "mgx_slab_exchange: %d planes a side (2, or 4 before a pass of two sweeps)", d);
+  if (c->world > 1 && n3 < d) return cfail(MGX_ELIMIT, "mgx_slab_exchange: a slab of %d planes cannot send %d", n3, d);
   HIPC_TRY(hipSetDevice(c->device));
   Plane p;
   if (c->rank > 0) {
-    if ((r = plane(lv, 1, 2, &p)) != MGX_OK) return r;
+    if ((r = plane(lv, 1, d, &p)) != MGX_OK) return r;
     NCCL_TRY(ncclSend(p.ptr, p.bytes, ncclChar, c->rank - 1, c->nccl, c->stream));
-    if ((r = plane(lv, -1, 2, &p)) != MGX_OK) return r;
+    if ((r = plane(lv, 1 - d, d, &p)) != MGX_OK) return r;
     NCCL_TRY(ncclRecv(p.ptr, p.bytes, ncclChar, c->rank - 1, c->nccl, c->stream));
   }
   if (c->rank < c->world - 1) {
-    if ((r = plane(lv, n3 + 1, 2, &p)) != MGX_OK) return r;
+    if ((r = plane(lv, n3 + 1, d, &p)) != MGX_OK) return r;
     NCCL_TRY(ncclRecv(p.ptr, p.bytes, ncclChar, c->rank + 1, c->nccl, c->stream));
-    if ((r = plane(lv, n3 - 1, 2, &p)) != MGX_OK) return r;
+    if ((r = plane(lv, n3 + 1 - d, d, &p)) != MGX_OK) return r;
     NCCL_TRY(ncclSend(p.ptr, p.bytes, ncclChar, c->rank + 1, c->nccl, c->stream));
   }
   return MGX_OK;
@@ -220,14 +223,14 @@ static int grouped(int n, mgx_level *const *lvs, mgx_comm *const *comms, F post)
   return MGX_OK;
 }
 
-extern "C" int mgx_slab_exchange(mgx_level *lv, mgx_comm *comm) {
-  if (comm && comm->world == 1) return MGX_OK;
-  return grouped(1, &lv, &comm, post_halo);
+extern "C" int mgx_slab_exchange(mgx_level *lv, mgx_comm *comm, int planes) {
+  if (comm && comm->world == 1 && (planes == 2 || planes == 4)) return MGX_OK;
+  return grouped(1, &lv, &comm, [&](mgx_level *l, mgx_comm *c) { return post_halo(l, c, planes); });
 }
 
-extern "C" int mgx_slab_exchange_all(int n, mgx_level *const *lvs, mgx_comm *const *comms) {
-  if (n == 1) return mgx_slab_exchange(lvs ? lvs[0] : nullptr, comms ? comms[0] : nullptr);
-  return grouped(n, lvs, comms, post_halo);
+extern "C" int mgx_slab_exchange_all(int n, mgx_level *const *lvs, mgx_comm *const *comms, int planes) {
+  if (n == 1) return mgx_slab_exchange(lvs ? lvs[0] : nullptr, comms ? comms[0] : nullptr, planes);
+  return grouped(n, lvs, comms, [&](mgx_level *l, mgx_comm *c) { return post_halo(l, c, planes); });
 }
 
 extern "C" int mgx_slab_periodic_ghosts(mgx_level *lv, mgx_comm *comm, int c0, int c1) {
@@ -240,29 +243,16 @@ extern "C" int mgx_slab_periodic_ghosts_all(int n, mgx_level *const *lvs, mgx_co
 
 // ---- reductions --------------------------------------------------------------------------------------------------
 
-static int stage_result(mgx_level *lv, mgx_comm *c) {
+// both reductions of one rank, from the level's own record into the communicator's copy; nothing visits the host
+static int post_reduce(mgx_level *lv, mgx_comm *c) {
   int32_t n3 = 0;
   int r = check_pair("mgx_allreduce_result", lv, c, &n3);
   if (r != MGX_OK) return r;
-  double e2 = 0, s = 0;
-  uint64_t limbs[2] = {0, 0};
-  MGX_TRY(mgx_level_result(lv, &e2, &s, limbs));      // waits for the slab's sweep
-  const double bad = (s != s) ? 1.0 : 0.0;
-  c->h_rec[W_DIGITS + 0] = limbs[0] & 0xffffffffu;
-  c->h_rec[W_DIGITS + 1] = limbs[0] >> 32;
-  c->h_rec[W_DIGITS + 2] = limbs[1] & 0xffffffffu;
-  c->h_rec[W_DIGITS + 3] = limbs[1] >> 32;
-  memcpy(&c->h_rec[W_MAX + 0], &e2, 8);
-  memcpy(&c->h_rec[W_MAX + 1], &bad, 8);
+  const uint64_t *rec = nullptr;
+  MGX_TRY(mgx_level_result_device(lv, &rec));           // enqueued behind the slab's sweep
   HIPC_TRY(hipSetDevice(c->device));
-  HIPC_TRY(hipMemcpyAsync(c->d_rec, c->h_rec, W_WORDS * sizeof(uint64_t), hipMemcpyHostToDevice, c->stream));
-  return MGX_OK;
-}
-
-static int post_reduce(mgx_level *, mgx_comm *c) {
-  HIPC_TRY(hipSetDevice(c->device));
-  NCCL_TRY(ncclAllReduce(c->d_rec + W_DIGITS, c->d_rec + W_DIGITS, 4, ncclUint64, ncclSum, c->nccl, c->stream));
-  NCCL_TRY(ncclAllReduce(c->d_rec + W_MAX, c->d_rec + W_MAX, 2, ncclDouble, ncclMax, c->nccl, c->stream));
+  NCCL_TRY(ncclAllReduce(rec + 1, c->d_rec + W_DIGITS, 4, ncclUint64, ncclSum, c->nccl, c->stream));
+  NCCL_TRY(ncclAllReduce(rec, c->d_rec + W_MAX, W_NMAX, ncclUint64, ncclMax, c->nccl, c->stream));
   return MGX_OK;
 }
 
@@ -270,15 +260,16 @@ static int fetch_result(mgx_comm *c, double *err_sq_max, double *abs_sum, uint64
   HIPC_TRY(hipSetDevice(c->device));
   HIPC_TRY(hipMemcpyAsync(c->h_rec, c->d_rec, W_WORDS * sizeof(uint64_t), hipMemcpyDeviceToHost, c->stream));
   HIPC_TRY(hipStreamSynchronize(c->stream));
-  // digits d0..d3 (each a sum of at most `world` 32-bit numbers) -> 128-bit integer
+  if (c->h_rec[W_GAVE_UP] != 0)
+    return cfail(MGX_EHIP, "mgx_allreduce_result: a sweep of some slab gave up waiting inside the kernel: the field is not valid");
+  // digits d0..d3 (each a sum of `world` numbers far below 2^56) -> 128-bit integer
   unsigned __int128 total = 0;
   for (int i = 3; i >= 0; --i) total = (total << 32) + (unsigned __int128)c->h_rec[W_DIGITS + i];
   uint64_t limbs[2] = {(uint64_t)total, (uint64_t)(total >> 64)};
-  double e2, bad;
-  memcpy(&e2, &c->h_rec[W_MAX + 0], 8);
-  memcpy(&bad, &c->h_rec[W_MAX + 1], 8);
+  double e2;
+  memcpy(&e2, &c->h_rec[W_E2], 8);
   if (err_sq_max) *err_sq_max = e2;
-  if (abs_sum) *abs_sum = bad != 0.0 ? std::nan("") : mgx_limbs_to_double(limbs);
+  if (abs_sum) *abs_sum = c->h_rec[W_BAD] != 0 ? std::nan("") : mgx_limbs_to_double(limbs);
   if (sum_limbs) { sum_limbs[0] = limbs[0]; sum_limbs[1] = limbs[1]; }
   return MGX_OK;
 }
@@ -286,10 +277,6 @@ static int fetch_result(mgx_comm *c, double *err_sq_max, double *abs_sum, uint64
 extern "C" int mgx_allreduce_result_all(int n, mgx_level *const *lvs, mgx_comm *const *comms, double *err_sq_max,
                                         double *abs_sum, uint64_t sum_limbs[2]) {
   if (n < 1 || !lvs || !comms) return cfail(MGX_EINVAL, "mgx_allreduce_result: bad argument list");
-  for (int i = 0; i < n; ++i) {
-    int r = stage_result(lvs[i], comms[i]);
-    if (r != MGX_OK) return r;
-  }
   int r = grouped(n, lvs, comms, post_reduce);
   if (r != MGX_OK) return r;
   // every rank holds the same record; ranks 1.. are waited for so that their buffers can be reused

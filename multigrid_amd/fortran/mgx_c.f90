@@ -151,6 +151,12 @@ module mgx_c
        type(c_ptr), value :: sum_limbs                     ! uint64_t[2] or c_null_ptr
        integer(c_int) :: rc
      end function mgx_level_result
+     function mgx_level_result_device(lv, record) bind(C, name="mgx_level_result_device") result(rc)
+       import :: c_int, c_ptr
+       type(c_ptr), value :: lv
+       type(c_ptr), intent(out) :: record                  ! device address of eight 64-bit words
+       integer(c_int) :: rc
+     end function mgx_level_result_device
      function mgx_level_abs_sum(lv, s) bind(C, name="mgx_level_abs_sum") result(rc)
        import :: c_int, c_double, c_ptr
        type(c_ptr), value :: lv

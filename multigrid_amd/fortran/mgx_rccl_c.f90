@@ -36,15 +36,17 @@ module mgx_rccl_c
        type(c_ptr), value :: comm
        integer(c_int) :: rc
      end function mgx_comm_destroy
-     function mgx_slab_exchange(lv, comm) bind(C, name="mgx_slab_exchange") result(rc)
+     function mgx_slab_exchange(lv, comm, planes) bind(C, name="mgx_slab_exchange") result(rc)
        import :: c_int, c_ptr
        type(c_ptr), value :: lv, comm
+       integer(c_int), value :: planes                     ! 2, or 4 before a pass of two sweeps
        integer(c_int) :: rc
      end function mgx_slab_exchange
-     function mgx_slab_exchange_all(n, lvs, comms) bind(C, name="mgx_slab_exchange_all") result(rc)
+     function mgx_slab_exchange_all(n, lvs, comms, planes) bind(C, name="mgx_slab_exchange_all") result(rc)
        import :: c_int, c_ptr
        integer(c_int), value :: n
        type(c_ptr), intent(in) :: lvs(*), comms(*)
+       integer(c_int), value :: planes
        integer(c_int) :: rc
      end function mgx_slab_exchange_all
      function mgx_slab_periodic_ghosts(lv, comm, c0_periodic, c1_periodic) bind(C, name="mgx_slab_periodic_ghosts") result(rc)

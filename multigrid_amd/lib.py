@@ -30,7 +30,7 @@ SYMBOLS = [
     "mgx_level_create", "mgx_level_create_slab", "mgx_level_destroy", "mgx_level_bring_back", "mgx_level_release",
     "mgx_level_set_params", "mgx_level_set_boxes", "mgx_level_setup", "mgx_level_sweep", "mgx_level_sweep_part",
     "mgx_level_half_sweep", "mgx_level_pair_pass",
-    "mgx_level_result_reset", "mgx_level_result", "mgx_level_abs_sum", "mgx_level_abs_sum_limbs",
+    "mgx_level_result_reset", "mgx_level_result", "mgx_level_result_device", "mgx_level_abs_sum", "mgx_level_abs_sum_limbs",
     "mgx_level_abs_sum_noalloc", "mgx_level_solve",
     "mgx_limbs_to_double", "mgx_level_count_nonconst", "mgx_level_tolerance", "mgx_restrict", "mgx_prolong",
     "mgx_level_upload", "mgx_level_download", "mgx_level_plane_ptr", "mgx_level_halo_written", "mgx_level_info",
@@ -85,6 +85,7 @@ def load():
         "mgx_level_pair_pass": [vp, pi32],
         "mgx_level_result_reset": [vp],
         "mgx_level_result": [vp, pdbl, pdbl, pu64],
+        "mgx_level_result_device": [vp, C.POINTER(vp)],
         "mgx_level_abs_sum": [vp, pdbl], "mgx_level_abs_sum_limbs": [vp, pu64],
         "mgx_level_abs_sum_noalloc": [vp, vp],
         "mgx_level_solve": [vp, dbl, i64, dbl, i64, i64, pdbl, C.POINTER(i64), pi32],
@@ -271,6 +272,12 @@ class DeviceLevel:
 
     def half_sweep(self, parity: int, zlo: int, zhi: int, reduce: int = 0):
         _ck(self.L.mgx_level_half_sweep(self.h, int(parity), int(zlo), int(zhi), int(reduce)))
+
+    def result_device(self) -> int:
+        """device address of the eight-word record of the last sweep (mgx_level_result_device); nothing waits"""
+        p = C.c_void_p()
+        _ck(self.L.mgx_level_result_device(self.h, C.byref(p)))
+        return int(p.value)
 
     def result_reset(self):
         _ck(self.L.mgx_level_result_reset(self.h))

@@ -36,7 +36,7 @@ def load():
     sig = {
         "mgx_comm_unique_id": [vp], "mgx_comm_create": [vp, C.c_int, C.c_int, vp, pvp],
         "mgx_comm_create_all": [C.c_int, pvp, pvp], "mgx_comm_destroy": [vp],
-        "mgx_slab_exchange": [vp, vp], "mgx_slab_exchange_all": [C.c_int, pvp, pvp],
+        "mgx_slab_exchange": [vp, vp, C.c_int], "mgx_slab_exchange_all": [C.c_int, pvp, pvp, C.c_int],
         "mgx_slab_periodic_ghosts": [vp, vp, C.c_int, C.c_int],
         "mgx_slab_periodic_ghosts_all": [C.c_int, pvp, pvp, C.c_int, C.c_int],
         "mgx_allreduce_result": [vp, vp, pdbl, pdbl, pu64],
@@ -81,8 +81,8 @@ class Comm:
         _ck(load().mgx_comm_create_all(n, arr, out))
         return [cls(C.c_void_p(out[i]), ctxs[i], i, n) for i in range(n)]
 
-    def exchange(self, lv):
-        _ck(load().mgx_slab_exchange(lv.h, self.h))
+    def exchange(self, lv, planes: int = 2):
+        _ck(load().mgx_slab_exchange(lv.h, self.h, int(planes)))
 
     def periodic_ghosts(self, lv, c0: bool, c1: bool):
         _ck(load().mgx_slab_periodic_ghosts(lv.h, self.h, int(c0), int(c1)))
@@ -99,9 +99,10 @@ class Comm:
             self.h = None
 
 
-def exchange_all(comms, lvs):
+def exchange_all(comms, lvs, planes: int = 2):
     n = len(comms)
-    _ck(load().mgx_slab_exchange_all(n, (C.c_void_p * n)(*[l.h for l in lvs]), (C.c_void_p * n)(*[c.h for c in comms])))
+    _ck(load().mgx_slab_exchange_all(n, (C.c_void_p * n)(*[l.h for l in lvs]), (C.c_void_p * n)(*[c.h for c in comms]),
+                                     int(planes)))
 
 
 def allreduce_result_all(comms, lvs):

@@ -25,6 +25,8 @@ from typing import Callable, List, Optional, Tuple
 
 import numpy as np
 
+import struct
+
 from . import grid as G
 from . import lib
 
@@ -236,7 +238,10 @@ class SlabLevel:
         (the communication backend orders its transfers after the kernels already enqueued on the current stream,
         so the inner launch, enqueued afterwards, runs beside them)."""
         red = self.reduce if reduce is None else reduce
-        if self.world == 1 or not self.overlap:
+        # (the edge part of a single sweep completes the two planes a side a neighbour needs for its next single sweep;
+        # where four are kept current for passes of two sweeps, planes 3, 4 and n3-3, n3-2 are ready only after the
+        # whole sweep: such a level's odd single sweeps are exchanged after it)
+        if self.world == 1 or not self.overlap or self.depth != 2:
             self.lv.sweep(1, red)
             self.exchange_halos()
             return
@@ -264,10 +269,31 @@ class SlabLevel:
 
     def result(self):
         """(max (vv-V)^2, sum|V|, exact sum in units of 2^-72) over the WHOLE level, identical on every rank"""
-        e2, s, units = self.lv.result()
         if self.world == 1:
-            return e2, s, units
+            return self.lv.result()
+        return self.result_over_ranks()
+
+    def result_over_ranks(self):
+        """the all-reduced record.  Over RCCL the slab's record is reduced where the sweep left it on the device
+        (mgx_level_result_device): no copy to the host and back before the collectives, one wait for the reduced
+        numbers.  Max dV^2 travels as the bits of a double that is never negative: integer order is its order."""
         import torch
+        if self._stream_ordered() and hasattr(self.lv, "result_device"):
+            ptr = self.lv.result_device()
+            rec = self.__dict__.get("_rec")
+            if rec is None or rec[0] != ptr:
+                t = torch.as_tensor(_DevicePlanes(ptr, 64), device=torch.device("cuda", self.lv.ctx.device)).view(torch.int64)
+                rec = self._rec = (ptr, t)
+            mx, dg = rec[1][:7].clone(), rec[1][1:5].clone()
+            self.dist.all_reduce(mx, op=self.dist.ReduceOp.MAX, group=self.group)
+            self.dist.all_reduce(dg, op=self.dist.ReduceOp.SUM, group=self.group)
+            v = torch.cat([mx, dg]).tolist()                       # the one wait
+            if v[6]:
+                raise lib.MgxError(-2, f"a sweep of level {self.grid.layer} gave up inside the kernel on some rank: the field is not valid")
+            total = sum(int(d) << (32 * i) for i, d in enumerate(v[7:11]))
+            e2g = struct.unpack("<d", struct.pack("<q", v[0]))[0]
+            return e2g, (float("nan") if v[5] else total / SUM_UNITS), total
+        e2, s, units = self.lv.result()
         dev = self._scalar_device()
         bad = 1.0 if (s != s) else 0.0
         mx = torch.tensor([e2, bad], dtype=torch.float64, device=dev)

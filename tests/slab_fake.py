@@ -103,11 +103,22 @@ class FakeSlabLevel:
         self._half_sweeps(2 * int(nsweeps), reduce)
 
     def sweep_part(self, part, reduce):
-        """edge part = the whole pass (the new boundary planes exist afterwards); inner part = nothing left to do"""
-        if part == 1:
-            self.sweep(1, reduce)
-        elif part == 3:
-            self.sweep(2, reduce)
+        """edge part = the whole pass, of which only the planes the library's edge launch completes are shown (two a
+        side of a single sweep, four of a pass of two): the others are NaN until the inner part, so that a host which
+        sends planes before they exist spoils the result"""
+        if part in (1, 3):
+            self.sweep(1 if part == 1 else 2, reduce)
+            keep = 2 if part == 1 else 4
+            lo, hi = OFF + keep + 1, OFF + self.n3 - keep + 1         # planes keep+1 .. n3-keep
+            self._due = (part + 1, lo, hi, self.V[lo:hi].copy()) if hi > lo else (part + 1, 0, 0, None)
+            if hi > lo:
+                self.V[lo:hi] = np.nan
+        else:
+            want, lo, hi, planes = self._due
+            assert part == want, "inner part without its edge part"
+            if planes is not None:
+                self.V[lo:hi] = planes
+            self._due = None
 
     def result(self):
         return self.res

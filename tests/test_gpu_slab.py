@@ -93,12 +93,25 @@ def test_slab_sweeps_equal_undivided(dtype, parts, two_launches):
 @pytest.mark.parametrize("parts", [[(0, 13), (13, 11)], [(0, 8), (8, 7), (15, 9)], [(0, 135), (135, 105)],
                                    [(0, 41), (41, 64), (105, 35)]])
 def test_slab_pair_passes_equal_undivided(dtype, parts, two_launches):
+    _pair_passes(dtype, parts, two_launches, (150, 45), (1, 1, 1, 1, 3, 2))
+
+
+# the coarse levels of a decomposed hierarchy: slabs of four or five planes, a handful of cells across
+@pytest.mark.parametrize("dtype", [np.float64, np.float32])
+@pytest.mark.parametrize("parts,n12,bc", [([(0, 5), (5, 5)], (8, 6), (2, 2, 2, 2, 2, 2)), ([(0, 4), (4, 4), (8, 6)], (16, 12), (2, 2, 1, 1, 1, 1)),
+                                          ([(0, 10), (10, 10)], (16, 12), (1, 1, 2, 2, 3, 3)), ([(0, 20), (20, 20)], (32, 24), (2, 2, 2, 2, 1, 1))])
+def test_thin_slab_pair_passes_equal_undivided(dtype, parts, n12, bc):
+    _pair_passes(dtype, parts, True, n12, bc)
+
+
+def _pair_passes(dtype, parts, two_launches, n12, bc):
     import torch
     from multigrid_amd import lib, slab
     from oracle import oracle as orc
-    n = (150, 45, sum(k for _, k in parts))
-    bc = (1, 1, 1, 1, 3, 2)
-    place = np.array([[40, 110, 10, 30, 1, 2], [40, 110, 10, 30, n[2] - 1, n[2]], [60, 90, 15, 25, 3, n[2] - 2]], dtype=np.int32)
+    n = (n12[0], n12[1], sum(k for _, k in parts))
+    x0, x1, y0, y1 = max(1, n[0] * 4 // 15), max(2, n[0] * 11 // 15), max(1, n[1] * 2 // 9), max(2, n[1] * 2 // 3)
+    place = np.array([[x0, x1, y0, y1, 1, 2], [x0, x1, y0, y1, n[2] - 1, n[2]],
+                      [(x0 + x1) // 2, x1 - 1, (y0 + y1) // 2, y1 - 1, 3, n[2] - 2]], dtype=np.int32)
     boxes = (place, [0.5, -0.5, 0.0], [1.0, 1.0, 3.0], [1, 1, 0])
     ctx = lib.Context(0, None)
     pair_ctx = lib.Context(0, None)
@@ -124,6 +137,12 @@ def test_slab_pair_passes_equal_undivided(dtype, parts, two_launches):
     for lv, (z0, k) in zip(slabs, parts):
         lv.upload(np.ascontiguousarray(V0[z0:z0 + k + 2]))
         lv.setup(False)
+    ctx.sync()
+    first, last = slabs[0], slabs[-1]        # periodic z: the ghost planes of the set-up that only the far slab can supply
+    if bc[4] == lib.BC_PERIODIC:
+        slab.device_plane_tensor(first, 0, 1).copy_(slab.device_plane_tensor(last, last.n3_local, 1))
+    if bc[5] == lib.BC_PERIODIC:
+        slab.device_plane_tensor(last, last.n3_local + 1, 1).copy_(slab.device_plane_tensor(first, 1, 1))
     exchange()
     for lv in slabs:
         lv.halo_written()

@@ -74,13 +74,16 @@ def test_fortran_slab_driver_over_the_library_exchange():
     from multigrid_amd import lib
     exe = os.path.join(ROOT, "multigrid_amd", "fortran", "slab_rccl")
     assert os.path.exists(exe), "build it first: make -C multigrid_amd/fortran"
-    n, sweeps = 64, 10
-    r = subprocess.run([exe, "1", str(n), str(sweeps)], capture_output=True, text=True, timeout=200)
-    assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
-    line = [l for l in r.stdout.splitlines() if "err_sq_max" in l][0].split()
-    e2, s = float(line[2]), float(line[4])
-    hexes = [l for l in r.stdout.splitlines() if "limbs" in l][0].split()
-    units = (int(hexes[2], 16) << 64) | int(hexes[3], 16)
+    n, sweeps = 64, 11
+    got = []
+    for pairs in ("0", "1"):       # "1": two sweeps per pass and per exchange of four planes, the odd last one alone
+        r = subprocess.run([exe, "1", str(n), str(sweeps), pairs], capture_output=True, text=True, timeout=200)
+        assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
+        line = [l for l in r.stdout.splitlines() if "err_sq_max" in l][0].split()
+        hexes = [l for l in r.stdout.splitlines() if "limbs" in l][0].split()
+        got.append((float(line[2]), float(line[4]), (int(hexes[2], 16) << 64) | int(hexes[3], 16)))
+    assert got[0] == got[1]
+    e2, s, units = got[0]
     ctx = lib.Context(0)
     lv = ctx.level(1, (n, n, n), np.float64)
     try:
@@ -96,3 +99,41 @@ def test_fortran_slab_driver_over_the_library_exchange():
         lv.close()
         ctx.close()
     assert units == wunits and s == ws and e2 == we2 and ws > 0
+
+
+@pytest.mark.gpu
+def test_python_slab_reduction_stays_on_the_device_over_rccl():
+    """multigrid_amd/slab.py over the RCCL backend (a process group of one rank: the collectives run, over one card):
+    the slab's record is all-reduced from where the sweep left it and must decode to what mgx_level_result holds"""
+    import socket
+    import torch
+    import torch.distributed as dist
+    from multigrid_amd import grid as G, lib, mgio, slab
+    from tests.helpers import load
+    sk = socket.socket()
+    sk.bind(("127.0.0.1", 0))
+    port = sk.getsockname()[1]
+    sk.close()
+    torch.cuda.set_device(0)
+    dist.init_process_group("nccl", init_method=f"tcp://127.0.0.1:{port}", rank=0, world_size=1,
+                            device_id=torch.device("cuda", 0))
+    ctx = None
+    try:
+        stream = torch.cuda.Stream()
+        torch.cuda.set_stream(stream)
+        ctx = lib.Context(0, stream.cuda_stream)
+        top = mgio.iomg_read(mgio.MgIO(text=str(load("solve_64_bu_f64")["input"])), dtype=np.float64)
+        sl = slab.SlabLevel(ctx, top, 0, 1)
+        sl.lv.bring_back()
+        sl.lv.setup(True)
+        for k in range(3):
+            sl.lv.sweep(1, lib.RED_ERR | lib.RED_SUM)
+            want = sl.lv.result()
+            got = sl.result_over_ranks()
+            assert got == want and want[2] > 0, (k, got, want)
+        assert sl._rec[1].is_cuda
+    finally:
+        if ctx is not None:
+            ctx.close()
+        torch.cuda.set_stream(torch.cuda.default_stream())
+        dist.destroy_process_group()
