@@ -14,6 +14,7 @@
 #include "mgx_kernels.hpp"
 #include "mgx_plan.hpp"
 #include "mgx_lex.hpp"
+#include "mgx_small.hpp"
 
 // ------------------------------------------------------------------------------------------------
 // errors
@@ -65,6 +66,7 @@ static u64 *g_scratch_ptr[MGX_MAX_DEVICES] = {nullptr};
 #define MGX_SLAB_EXTRA 2        /* planes a slab holds beyond -1 and n3 + 2 on either side */
 static unsigned long long g_level_uid = 0;   // the next level's uid
 static int mgx_lex_tiled = 2;    // the reference-order sweep: 2 all tiles in one launch (k_lex_chain), 1 a launch per tile hyperplane, 0 per cell hyperplane
+static int mgx_solve_loop = 1;   // 0: mgx_level_solve launches every sweep, 1: one launch where the level fits (default)
 static int mgx_pair_pass = -1;   // 0: never two sweeps per pass, 1: wherever the kernel applies, -1: where it pays (default)
 
 // ------------------------------------------------------------------------------------------------
@@ -199,6 +201,7 @@ extern "C" int mgx_ctx_create(int device, void *stream, mgx_ctx **out) {
   if (const char *e = getenv("MGX_FUSED_ORDER")) mgx_fused_order = atoi(e);
   if (const char *e = getenv("MGX_FUSED_BOXCUT")) mgx_fused_boxcut = atoi(e);
   if (const char *e = getenv("MGX_LEX_TILED")) mgx_lex_tiled = atoi(e);
+  if (const char *e = getenv("MGX_SOLVE_LOOP")) mgx_solve_loop = atoi(e);  // 0: a launch per sweep in mgx_level_solve
   if (const char *e = getenv("MGX_PAIR_PASS")) mgx_pair_pass = atoi(e);   // 0 off, 1 on every level the kernel takes
   // initial kernel selection (MGX_KERNEL_*), for hosts that have no call of mgx_ctx_set_kernel of their own:
   // MGX_KERNEL=4 runs the reference's program over this library in the reference's sweep order
@@ -932,31 +935,49 @@ extern "C" int mgx_level_half_sweep(mgx_level *lv, int parity, int32_t zlo, int3
 // followed by a one-block kernel that evaluates the convergence test on the device and, once it is met, raises a flag
 // that voids the sweeps still queued behind it.  The host reads one small record per batch.
 #define MGX_SOLVE_BATCH 24
+#define MGX_SOLVE_LOOP_BATCH 1024   /* sweeps per launch of the one-launch loop (k_small_solve) */
+#define MGX_SMALL_MAX_CELLS 600000   /* levels up to this many cells take it: beyond, a sweep is bytes, not latency */
 template <typename T>
 static int do_solve(mgx_level *lv, double tol_level, double nr, double old_sum, long long max_sweeps, long long hist_cap,
                     double *hist, long long *nsweeps, int *status) {
   mgx_ctx *c = C(lv);
   const MgxGeom &g = lv->g;
   hipStream_t st = c->stream;
-  if (!lv->d_solve) HIP_TRY(hipMalloc((void **)&lv->d_solve, sizeof(MgxSolveState) + sizeof(double) * 3 * MGX_SOLVE_BATCH));
-  if (!c->h_solve) HIP_TRY(hipHostMalloc((void **)&c->h_solve, sizeof(MgxSolveState) + sizeof(double) * 3 * MGX_SOLVE_BATCH, hipHostMallocDefault));
+  constexpr size_t state_bytes = sizeof(MgxSolveState) + sizeof(double) * 3 * MGX_SOLVE_LOOP_BATCH;
+  static_assert(MGX_SOLVE_LOOP_BATCH >= MGX_SOLVE_BATCH, "history buffer");
+  if (!lv->d_solve) HIP_TRY(hipMalloc((void **)&lv->d_solve, state_bytes));
+  if (!c->h_solve) HIP_TRY(hipHostMalloc((void **)&c->h_solve, state_bytes, hipHostMallocDefault));
   double *d_hist = reinterpret_cast<double *>(lv->d_solve + 1);
   TRY(sync_shell<T>(lv));
   if (!lv->plan.valid && make_plan(lv, lv->plan, 1) != 0)
     return fail(MGX_EHIP, "mgx_level_solve: could not build the tile lists of the fused kernel");
   MgxSolveState init;
-  init.stop = 0; init.count = 0; init.old_sum = (double)(T)old_sum;
+  init.stop = 0; init.count = 0; init.old_sum = (double)(T)old_sum; init.arrive = 0; init.gen = 0;
   HIP_TRY(hipMemcpyAsync(lv->d_solve, &init, sizeof init, hipMemcpyHostToDevice, st));
   HIP_TRY(hipStreamSynchronize(st));                       // `init` is a local
   TRY(prepare_single_pass(lv));
   const MgxSweepParams<T> p = make_params<T>(lv);
   long long done = 0;
   *status = 0;
+  bool one_launch = mgx_solve_loop != 0;     // levels whose pieces fit on the device at once: the loop in one launch
   for (;;) {
-    const int batch = (int)std::min<long long>(MGX_SOLVE_BATCH, max_sweeps - done);
+    int batch = (int)std::min<long long>(one_launch ? MGX_SOLVE_LOOP_BATCH : MGX_SOLVE_BATCH, max_sweeps - done);
     if (batch <= 0) { *status = 1; break; }
     const int cur0 = lv->cur;
-    for (int j = 0; j < batch; ++j) {
+    if (one_launch) {
+      // every block must be on the device while the others wait for it: at most one per compute unit
+      int cus = 0;
+      HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device));
+      const long long ncol = (long long)((g.n1 + 1) / 2) * g.n2 * g.n3;
+      const long long blocks = std::min<long long>(cus, (ncol + 511) / 512);
+      if (ncol > MGX_SMALL_MAX_CELLS / 2 || blocks * 256 * MGX_SMALL_CPT < ncol || g.n1 > 1000 || g.n2 > 1000 || g.n3 > 1000) {
+        one_launch = false;
+        continue;
+      }
+      hipLaunchKernelGGL((k_small_solve<T>), dim3((unsigned)blocks), dim3(256), 0, st, (T *)lv->buf[cur0], g, p, lv->d_boxes,
+                         lv->nbox, lv->d_res, lv->d_solve, d_hist, MGX_SOLVE_LOOP_BATCH, tol_level, nr, batch);
+    }
+    for (int j = 0; j < batch && !one_launch; ++j) {
       const int a = cur0 ^ (j & 1);
       if (mgx_fused_launch(lv->plan, 0, (const T *)lv->buf[a], (T *)lv->buf[1 - a], g, p, lv->d_boxes, lv->nbox,
                            MGX_RED_ERR | MGX_RED_SUM, lv->d_res, st, &lv->d_solve->stop) != 0)
@@ -974,10 +995,14 @@ static int do_solve(mgx_level *lv, double tol_level, double nr, double old_sum, 
       if (done + i < hist_cap)
         for (int k = 0; k < 3; ++k) hist[3 * (done + i) + k] = hh[3 * i + k];
     done += cnt;
-    lv->cur = cur0 ^ (cnt & 1);                             // the sweeps behind the flag left the buffers alone
+    if (!one_launch) lv->cur = cur0 ^ (cnt & 1);            // the sweeps behind the flag left the buffers alone
+    if (one_launch && (hs->gen >> 28) == 3u)
+      return fail(MGX_EHIP, "mgx_level_solve: a block of the one-launch loop gave up waiting for the others (level %d): "
+                  "the field of this level is not valid", lv->layer);
     if (hs->stop == 2) { *status = 2; break; }
     if (hs->stop == 1) break;
     HIP_TRY(hipMemsetAsync(&lv->d_solve->count, 0, sizeof(int), st));   // next batch: history from slot 0 again
+    HIP_TRY(hipMemsetAsync(&lv->d_solve->arrive, 0, 2 * sizeof(unsigned), st));
   }
   *nsweeps = done;
   return MGX_OK;

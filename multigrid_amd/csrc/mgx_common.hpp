@@ -123,6 +123,7 @@ __device__ inline void mgx_fast_sum_flush(double &h, double &l, u64 &lo, u64 &hi
 //   [1..4] the 128-bit sum as four 32-bit digits kept in 64-bit words (carries deferred)
 //   [5] overflow flag of the sum
 #define MGX_RES_WORDS 8
+#define MGX_RES_ERRWORD 6                /* word of record 0 a kernel raises when it had to give up waiting */
 // Blocks commit into one of MGX_RES_SLOTS replicas of the record (by block index) so that thousands of
 // blocks do not queue on one address; a one-block kernel folds the replicas into record 0 before read-back.
 #define MGX_RES_SLOTS 128

@@ -97,9 +97,10 @@ __device__ inline void mgx_block_commit(double err, u64 lo, u64 hi, unsigned ovf
 #pragma unroll
       for (int k = 0; k < 5; ++k) d[k] = mgx_wave_add(d[k]);
       if (lane == 0) {
-        res[0] = m;
+        // (device-scope stores: a block on another compute unit may read the record later in the same launch)
+        __hip_atomic_store(&res[0], m, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 #pragma unroll
-        for (int k = 0; k < 5; ++k) res[1 + k] = d[k];
+        for (int k = 0; k < 5; ++k) __hip_atomic_store(&res[1 + k], d[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         atomicExch(&res[MGX_RES_CNT], 0ull);
       }
     }
@@ -167,19 +168,19 @@ __device__ inline double mgx_limbs_to_double_dev(const u64 lo, const u64 hi) {
 }
 
 struct MgxSolveState {      // device memory, one per level that mgx_level_solve has run on
-  int stop;                 // 0: keep sweeping; 1: the test was met; 2: the sum left its exact range
+  int stop;                 // 0: keep sweeping; 1: the test was met; 2: the sum left its exact range; 3: gave up waiting
   int count;                // sweeps of this batch that took effect
   double old_sum;           // grid_sum before the next sweep, already rounded to the level's precision
+  unsigned arrive;          // the one-launch loop (k_fused_solve): blocks that have finished their sweeps, counted up
+  unsigned gen;             // ... and sweeps of this launch whose test is done (low 28 bits), its verdict above
 };
 
 // After a sweep with both reductions (whose last block has folded the result into record 0): evaluate
 // tol = |old_sum - new_sum| * nr in the level's precision T (m_gs_CDS.F90:206-207), append (tol, new_sum, max dV^2) to
 // the batch's history and raise `stop` when the loop condition `tol > gtol` (:200) fails.  One thread.
 template <typename T>
-__global__ __launch_bounds__(64) void k_solve_check(const u64 *__restrict__ res, MgxSolveState *__restrict__ stt,
-                                                    double *__restrict__ hist, const int cap, const double gtol,
-                                                    const double nr) {
-  if (threadIdx.x != 0 || stt->stop != 0) return;
+__device__ inline int mgx_solve_check(const u64 *__restrict__ res, MgxSolveState *__restrict__ stt,
+                                      double *__restrict__ hist, const int cap, const double gtol, const double nr) {
   const u64 mm = res[0];
   const u64 dd[5] = {res[1], res[2], res[3], res[4], res[5]};
   // positional sum of the four digits (they may exceed 32 bits)
@@ -196,7 +197,17 @@ __global__ __launch_bounds__(64) void k_solve_check(const u64 *__restrict__ res,
   if (i < cap) { hist[3 * i] = (double)tol; hist[3 * i + 1] = (double)new_sum; hist[3 * i + 2] = __longlong_as_double((long long)mm); }
   stt->count = i + 1;
   stt->old_sum = (double)new_sum;
-  stt->stop = bad ? 2 : ((double)tol > gtol ? 0 : 1);
+  const int stop = bad ? 2 : ((double)tol > gtol ? 0 : 1);
+  stt->stop = stop;
+  return stop;
+}
+
+template <typename T>
+__global__ __launch_bounds__(64) void k_solve_check(const u64 *__restrict__ res, MgxSolveState *__restrict__ stt,
+                                                    double *__restrict__ hist, const int cap, const double gtol,
+                                                    const double nr) {
+  if (threadIdx.x != 0 || stt->stop != 0) return;
+  (void)mgx_solve_check<T>(res, stt, hist, cap, gtol, nr);
 }
 
 // ------------------------------------------------------------------------------------------------

@@ -22,7 +22,6 @@
 #define MGX_LEXC_CY 8
 #define MGX_LEXC_CZ 8
 #define MGX_LEXC_MAXSPIN (1 << 19)       /* polls before a tile gives up (each takes a microsecond or more) */
-#define MGX_RES_ERRWORD 6                /* word of the result record a kernel raises when it had to give up */
 
 template <typename T>
 struct MgxLexcBoxLds {
