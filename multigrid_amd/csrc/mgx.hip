@@ -747,10 +747,10 @@ static int lex_sweep(mgx_level *lv, int reduce) {
     const long long nt = (long long)lv->lex_nt[0] * lv->lex_nt[1] * lv->lex_nt[2];
     const int epoch = ++lv->lex_epoch;
     if (lv->nbox > 0)
-      hipLaunchKernelGGL((k_lex_chain<T, true>), dim3((unsigned)nt), dim3(64), 0, st, (T *)lv->buf[lv->cur], g, p, lv->d_boxes,
+      hipLaunchKernelGGL((k_lex_chain<T, true>), dim3((unsigned)nt), dim3(MGX_LEXC_NT), 0, st, (T *)lv->buf[lv->cur], g, p, lv->d_boxes,
                          lv->nbox, lv->d_lex, lv->d_lex + nt, epoch, lv->lex_nt[0], lv->lex_nt[1], reduce & MGX_RED_ERR, lv->d_res);
     else
-      hipLaunchKernelGGL((k_lex_chain<T, false>), dim3((unsigned)nt), dim3(64), 0, st, (T *)lv->buf[lv->cur], g, p, lv->d_boxes,
+      hipLaunchKernelGGL((k_lex_chain<T, false>), dim3((unsigned)nt), dim3(MGX_LEXC_NT), 0, st, (T *)lv->buf[lv->cur], g, p, lv->d_boxes,
                          lv->nbox, lv->d_lex, lv->d_lex + nt, epoch, lv->lex_nt[0], lv->lex_nt[1], reduce & MGX_RED_ERR, lv->d_res);
   } else
   if (mgx_lex_tiled) {      // a launch per tile hyperplane (k_lex_tile); MGX_LEX_TILED=0 selects the cell hyperplanes (k_lex_plane)

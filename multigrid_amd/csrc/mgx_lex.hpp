@@ -1,8 +1,8 @@
 // The reference's own sweep order (gs, m_gs_CDS.F90:317-345: in place, z outermost, x innermost) in ONE launch per
-// sweep.  The level is cut into tiles of one 128-byte line x 8 rows x 8 planes; a tile needs the new values of the
+// sweep.  The level is cut into tiles of one 128-byte line x 16 rows x 16 planes; a tile needs the new values of the
 // tiles before it in x, y and z and the old ones of the tiles behind it, exactly as a cell does.  k_lex_tile launches
 // the tile hyperplanes I + J + K = D one after the other (190 launches at 512^3); here all tiles are one grid,
-// dispatched in hyperplane order, one wave per tile, and a tile waits for its three predecessors through a counter
+// dispatched in hyperplane order, one block per tile (a thread per row and plane), and a tile waits for its three predecessors through a counter
 // per tile: every sweep adds one to the counter of every tile, so "done in sweep e" reads "counter >= e" and nothing
 // is reset between sweeps.  Blocks are dispatched in index order and a tile only waits for tiles earlier in that
 // order, so the wait ends; should it not (a bound of polls), the tile gives up, raises the error word of the level's
@@ -19,27 +19,34 @@
 
 #include "mgx_kernels.hpp"
 
-#define MGX_LEXC_CY 8
-#define MGX_LEXC_CZ 8
+#ifndef MGX_LEXC_CY
+#define MGX_LEXC_CY 16                   /* rows and planes of a tile: one thread per (row, plane), CY * CZ a block */
+#define MGX_LEXC_CZ 16
+#endif
+#define MGX_LEXC_NT (MGX_LEXC_CY * MGX_LEXC_CZ)
 #define MGX_LEXC_MAXSPIN (1 << 19)       /* polls before a tile gives up (each takes a microsecond or more) */
 
 template <typename T>
 struct MgxLexcBoxLds {
   unsigned xs[128 / sizeof(T) + 2], ys[MGX_LEXC_CY + 2], zs[MGX_LEXC_CZ + 2];
   T wtab[2][64][6];
-  unsigned short code[MGX_LEXC_CZ * MGX_LEXC_CY * (128 / sizeof(T))];
+  // per cell: bit 7 = constant cell, bits 0..6 = row of wtab (table << 6 | mask of the neighbours inside that table's
+  // box); row 64 (second table, no neighbour inside: cannot occur) stands for "general weights"
+  unsigned char code[MGX_LEXC_CZ * MGX_LEXC_CY * (128 / sizeof(T))];
 };
 
 typedef unsigned mgx_lx_u4 __attribute__((ext_vector_type(4)));
 
 // `order`: the tiles in dispatch order, I | J << 10 | K << 20.  `done`: one counter per tile, index I + ntx (J + nty K).
 template <typename T, bool BOXED>
-__global__ __launch_bounds__(64) void k_lex_chain(T *__restrict__ V, const MgxGeom g, const MgxSweepParams<T> p,
+__global__ __launch_bounds__(MGX_LEXC_NT) void k_lex_chain(T *__restrict__ V, const MgxGeom g, const MgxSweepParams<T> p,
                                                   const MgxBox *__restrict__ bx, const int nb,
                                                   const int *__restrict__ order, int *__restrict__ done,
                                                   const int epoch, const int ntx, const int nty, const int reduce,
                                                   u64 *__restrict__ res) {
-  constexpr int TX = 128 / (int)sizeof(T), TY = MGX_LEXC_CY, TZ = MGX_LEXC_CZ;
+  constexpr int TX = 128 / (int)sizeof(T), TY = MGX_LEXC_CY, TZ = MGX_LEXC_CZ, NT = MGX_LEXC_NT;
+  static_assert(NT % 64 == 0 && NT <= 1024, "one thread per (row, plane) of a tile, whole waves");
+  __shared__ int lost_;
   constexpr int PX = TX + 3, PY = (TY + 2) * PX;          // pitches of the staged tile (row, plane), in elements
   constexpr int WPE = (int)sizeof(T) / 4;                  // 32-bit words per element
   __shared__ T t[(TZ + 2) * PY];
@@ -53,18 +60,19 @@ __global__ __launch_bounds__(64) void k_lex_chain(T *__restrict__ V, const MgxGe
   const int self = I + ntx * (J + nty * K);
   T err = (T)0;
   if (BOXED && lane < nb) sbx[lane] = bx[lane];
+  if (lane == 0) lost_ = 0;
 
   // ---- what was written before this launch: own cells and the faces towards x+1, y+1, z+1 (plain loads) ----
   {
     const T *const org = V + g.idx(x0 - 1, y0 - 1, z0 - 1);
-    constexpr int RW = TX + 1, BATCH = 8, NB = ((TY + 1) * (TZ + 1) * RW + 64 * BATCH - 1) / (64 * BATCH);
+    constexpr int RW = TX + 1, BATCH = 8, NB = ((TY + 1) * (TZ + 1) * RW + NT * BATCH - 1) / (NT * BATCH);
 #pragma unroll 1
     for (int b = 0; b < NB; ++b) {
       T tmp[BATCH];
       int at[BATCH];
 #pragma unroll
       for (int u = 0; u < BATCH; ++u) {
-        const int e = (b * BATCH + u) * 64 + lane;
+        const int e = (b * BATCH + u) * NT + lane;
         const int xx = e % RW + 1, r = e / RW, yy = r % (TY + 1) + 1, zz = r / (TY + 1) + 1;   // 1 .. n + 1
         const bool ok = xx < nx + 2 && yy < ny + 2 && zz < nz + 2;
         at[u] = ok ? zz * PY + yy * PX + xx : -1;
@@ -77,8 +85,7 @@ __global__ __launch_bounds__(64) void k_lex_chain(T *__restrict__ V, const MgxGe
   }
 
   // ---- wait for the tiles before this one in x, y, z ----
-  bool lost = false;
-  {
+  if (lane < 64) {                                         // (the first wave polls; the others wait at the barrier)
     int want = -1;
     if (lane == 0 && I > 0) want = self - 1;
     if (lane == 1 && J > 0) want = self - ntx;
@@ -91,7 +98,7 @@ __global__ __launch_bounds__(64) void k_lex_chain(T *__restrict__ V, const MgxGe
       // (a tile that finds the error word raised does not wait at all: a launch that lost one tile drains at once)
       if (++spins > MGX_LEXC_MAXSPIN ||
           ((spins & 255) == 0 && __hip_atomic_load(res + MGX_RES_ERRWORD, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0ull)) {
-        lost = true;
+        if (lane == 0) lost_ = 1;
         break;
       }
       __builtin_amdgcn_s_sleep(2);
@@ -106,10 +113,10 @@ __global__ __launch_bounds__(64) void k_lex_chain(T *__restrict__ V, const MgxGe
     const unsigned long long base = (unsigned long long)(V + g.idx(x0 - 1, y0 - 1, z0 - 1));
     const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
         (void *)base, 0, (int)min((long long)0x7fffffff, (long long)sizeof(T) * ((long long)(TZ + 2) * g.pz)), 0x00020000);
-    constexpr int PER = (TY * TZ + 2 * TX * TZ + 63) / 64;          // TY = TZ: bound of n_all / 64
+    constexpr int PER = (TY * TZ + TX * TZ + TX * TY + NT - 1) / NT;   // bound of n_all / NT
 #pragma unroll
     for (int u = 0; u < PER; ++u) {
-      const int e = u * 64 + lane;
+      const int e = u * NT + lane;
       int xx = 0, yy = 0, zz = 0;
       const bool ok = e < n_all;
       if (e < n_a) { xx = 0; yy = e % ny + 1; zz = e / ny + 1; }
@@ -128,7 +135,7 @@ __global__ __launch_bounds__(64) void k_lex_chain(T *__restrict__ V, const MgxGe
   __syncthreads();
 
   const int cls = BOXED ? mgx_classify(sbx, nb, x0, x0 + nx - 1, y0, y0 + ny - 1, z0 + g.z0, z0 + nz - 1 + g.z0) : 0;
-  const int j = lane & 7, k = lane >> 3;
+  const int j = lane % TY, k = lane / TY;
   const bool coded = BOXED && cls != 0;
   if constexpr (BOXED) {
     if (coded) {
@@ -148,7 +155,7 @@ __global__ __launch_bounds__(64) void k_lex_chain(T *__restrict__ V, const MgxGe
         (dim == 0 ? bl.xs : dim == 1 ? bl.ys : bl.zs)[l] = set;
       }
 #pragma unroll
-      for (int h = 0; h < 2; ++h) {
+      for (int h = 0; h < 2 && lane < 64; ++h) {
         const int m = lane;
         const unsigned tb = h ? tb1 : tb0;
         const T rb = tb ? (T)sbx[__ffs((int)tb) - 1].rho : (T)1;
@@ -164,9 +171,10 @@ __global__ __launch_bounds__(64) void k_lex_chain(T *__restrict__ V, const MgxGe
       if (j < ny && k < nz) {
         const uint4 ys4 = make_uint4(bl.ys[j], bl.ys[j + 1], bl.ys[j + 2], 0u);
         const unsigned zl = bl.zs[k], zc = bl.zs[k + 1], zh = bl.zs[k + 2];
-        for (int i = 0; i < nx; ++i)
-          bl.code[(k * TY + j) * TX + i] =
-              (unsigned short)mgx_cell_code(bl.xs[i + 1], bl.xs[i], bl.xs[i + 2], ys4, zl, zc, zh, cmask, rmask, tb0, tb1);
+        for (int i = 0; i < nx; ++i) {
+          const unsigned c9 = mgx_cell_code(bl.xs[i + 1], bl.xs[i], bl.xs[i + 2], ys4, zl, zc, zh, cmask, rmask, tb0, tb1);
+          bl.code[(k * TY + j) * TX + i] = (unsigned char)((c9 & MGX_CODE_GENERAL) ? ((c9 & MGX_CODE_CONST) | 64u) : (c9 & 255u));
+        }
       }
       __syncthreads();
     }
@@ -192,7 +200,7 @@ __global__ __launch_bounds__(64) void k_lex_chain(T *__restrict__ V, const MgxGe
           avg = avg + c[PX] * w[3];
           avg = avg + c[-PY] * w[4];
           avg = avg + c[PY] * w[5];
-          if (code & MGX_CODE_GENERAL)
+          if ((code & 127u) == 64u)
             avg = mgx_avg_general<T>(c[-1], c[1], c[-PX], c[PX], c[-PY], c[PY], sbx, nb, x0 + i, y0 + j, z0 + k + g.z0, p.a);
           avg = (code & MGX_CODE_CONST) ? vc : avg;
           vv = p.s1 * vc + p.s2 * avg;
@@ -215,8 +223,9 @@ __global__ __launch_bounds__(64) void k_lex_chain(T *__restrict__ V, const MgxGe
         (void *)base, 0, (int)min((long long)0x7fffffff, (long long)sizeof(T) * ((long long)TZ * g.pz)), 0x00020000);
     constexpr int EPL = 16 / (int)sizeof(T);             // elements per 16 bytes
     constexpr int LPR = TX / EPL;                        // lanes per row (8)
-    constexpr int ROWS = 64 / LPR;                       // rows per store instruction (8)
+    constexpr int ROWS = NT / LPR;                       // rows per store instruction
     const int sub = lane % LPR, rsel = lane / LPR;
+    static_assert((TY * TZ) % ROWS == 0, "rows of a tile in whole store instructions");
 #pragma unroll
     for (int u = 0; u < TY * TZ / ROWS; ++u) {
       const int r = u * ROWS + rsel, yy = r % TY, zz = r / TY;
@@ -250,7 +259,7 @@ __global__ __launch_bounds__(64) void k_lex_chain(T *__restrict__ V, const MgxGe
   __syncthreads();
   if (lane == 0) {
     __hip_atomic_fetch_add(done + self, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (lost) __hip_atomic_fetch_or(res + MGX_RES_ERRWORD, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (lost_) __hip_atomic_fetch_or(res + MGX_RES_ERRWORD, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
-  if (reduce & 1) mgx_block_commit<1>((double)err, 0ull, 0ull, 0u, 1, res);
+  if (reduce & 1) mgx_block_commit<NT / 64>((double)err, 0ull, 0ull, 0u, 1, res);
 }
