@@ -32,7 +32,7 @@ __device__ inline u64 mgx_wave_add(u64 v) {
 // the folded result to record 0 and clears the count.  Nothing has to be zeroed before such a launch and nothing
 // folded after it.
 template <int NW>
-__device__ inline void mgx_block_commit(double err, u64 lo, u64 hi, unsigned ovf, int reduce, u64 *res,
+__device__ __forceinline__ void mgx_block_commit(double err, u64 lo, u64 hi, unsigned ovf, int reduce, u64 *res,
                                         const int expected = 0) {
   __shared__ u64 sh[NW][6];
   const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;

@@ -14,13 +14,18 @@
 // stage only reads what was written before the step's single barrier.
 //
 // Lanes.  As in the one-sweep kernel a lane owns x-pairs (odd cell, even cell: 16 bytes in fp64, loaded and stored
-// whole) and keeps the z column of each pair in registers: planes k+1 .. k-L plus the planes in flight.  Row waves
-// own rows w, w + NW, ... of the staged region (64 pairs of the tile proper per row), one more wave owns the
-// 2 NS halo pairs of every row.  Rows of a wave share the parity of y, and the step loop is unrolled twice, so
-// "which cell of the pair has the colour of this step" is a compile-time constant (all stages of a step update
-// the same position of their pairs: the colour alternates with the stage and the position of a colour with the
-// plane).  The register window moves down one plane per step by copies; only the sets that receive the loads
+// whole) and keeps the z column of each pair in registers: planes k+1 .. k-L plus the planes in flight.  A row wave
+// owns a strip of RW = LR / NW neighbouring rows of the staged region (64 pairs of the tile proper per row; 30 staged
+// rows over 15 row waves of two rows each in the shipped shape), one more wave owns the 2 NS halo pairs of every
+// row.  Rows of a strip being neighbours, a cell's y neighbours inside the strip come from the lane's own registers
+// and only the strip's two edge rows are read from LDS.  The step loop is unrolled twice, so "which cell of pair j
+// has the colour of this step" is a compile-time constant, (P0 + u + j) & 1 (all stages of a step update the same
+// position of their pairs: the colour alternates with the stage and the position of a colour with the plane and the
+// row).  The register window moves down one plane per step by copies; only the sets that receive the loads
 // alternate by step parity, so that no copy waits for a load just issued.
+// The strips at either end of the staged region hold ring rows that only the early half-sweeps need: their waves get
+// bodies of their own (template parameter ROW0) that leave those rows out at compile time, and the dispatcher gives
+// these light strips to the last row waves of the block.
 //
 // Boxes (t_mg.f90:634-710): bit sets and per-cell codes exactly as in the one-sweep kernel (mgx_cell_code,
 // mgx_cell_from_code); a lane keeps the codes of both cells of its pairs for the planes k .. k-L and takes the
@@ -102,12 +107,17 @@ template <typename P> __device__ __forceinline__ P *mgx_uni(P *const v) { return
 // ROW0: the first staged row of the wave's strip where that is known at compile time (the strips at either end of the
 // staged region), else -1.  Half-sweep s works on the staged rows s + 1 .. LR - 2 - s, so the strips at the ends hold
 // rows that only the early half-sweeps need: those waves leave out the rows a stage does not need, at compile time.
+// what a wave contributes to the block's reductions: handed back to the kernel, which commits once for the block (one
+// copy of mgx_block_commit per kernel instead of one call per body variant: as a function of its own it saved and
+// restored 45 registers per lane through scratch memory, 0.35 GB of traffic per pass at 512^3)
+struct MgxTbOut { double e2 = 0.0; u64 lo = 0, hi = 0; unsigned ovf = 0; };
+
 template <typename T, int NS, int TY, int BOXES, int NW, int DF, int P0, bool HALO, bool FREE = false, int ROW0 = -1>
 __device__ MGX_TB_BODY_ATTR void mgx_tb_body(const T *__restrict__ src_, T *__restrict__ dst_, const MgxGeom g_,
                                             const MgxSweepParams<T> p_, const MgxBox *__restrict__ bx_, const int nb_,
                                             const int tx0_, const int ty0_, const int zc0_, const int zc1_,
                                             const int reduce_, u64 *__restrict__ res_, T *__restrict__ lds,
-                                            MgxBoxLds<T> *__restrict__ bl, const int n_commit_, const int strip_) {
+                                            MgxBoxLds<T> *__restrict__ bl, const int n_commit_, const int strip_, MgxTbOut &out) {
   const int strip = MGX_TB_UNI(strip_);             // the strip of rows of a row wave (see mgx_tb_tile)
   const T *__restrict__ src = MGX_TB_UNI(src_);
   T *__restrict__ dst = MGX_TB_UNI(dst_);
@@ -120,7 +130,11 @@ __device__ MGX_TB_BODY_ATTR void mgx_tb_body(const T *__restrict__ src_, T *__re
   for (int i = 0; i < 3; ++i) { p.a[i] = MGX_TB_UNI(p_.a[i]); p.w[i] = MGX_TB_UNI(p_.w[i]); }
   const MgxBox *__restrict__ bx = MGX_TB_UNI(bx_);
   const int nb = MGX_TB_UNI(nb_), tx0 = MGX_TB_UNI(tx0_), ty0 = MGX_TB_UNI(ty0_), zc0 = MGX_TB_UNI(zc0_), zc1 = MGX_TB_UNI(zc1_);
+#ifdef MGX_TB_RED_CONST
+  const int reduce = MGX_TB_RED_CONST | (MGX_TB_UNI(reduce_) & ~3), n_commit = MGX_TB_UNI(n_commit_);
+#else
   const int reduce = MGX_TB_UNI(reduce_), n_commit = MGX_TB_UNI(n_commit_);
+#endif
   u64 *__restrict__ res = MGX_TB_UNI(res_);
   typedef typename MgxVec2<T>::type V2;
   constexpr int TXP = 64;
@@ -707,7 +721,10 @@ __device__ MGX_TB_BODY_ATTR void mgx_tb_body(const T *__restrict__ src_, T *__re
       mgx_block_exact_sum<T>(dst, g, tx0, min(tx0 + 2 * TXP - 1, g.n1), ty0, min(ty0 + TY - 1, g.n2), zc0, zc1, slo, shi, ovf);
     }
   }
-  if (reduce & 3) mgx_block_commit<MGX_TB_WAVES(NW)>((double)(err * err), slo, shi, ovf, reduce & 3, res, n_commit);
+  out.e2 = (double)(err * err);
+  out.lo = slo;
+  out.hi = shi;
+  out.ovf = ovf;
 }
 
 // ---- the wave that loads nothing for itself ----
@@ -721,7 +738,7 @@ template <typename T, int NS, int TY, int NW>
 __device__ __attribute__((noinline)) void mgx_tb_prefetch_wave(const T *__restrict__ src_, T *__restrict__ dst_, const MgxGeom g_,
                                                                const int tx0_, const int ty0_, const int zc0_, const int zc1_,
                                                                const int reduce_, u64 *__restrict__ res_,
-                                                               MgxBoxLds<T> *__restrict__ bl, const int n_commit_) {
+                                                               MgxBoxLds<T> *__restrict__ bl, const int n_commit_, MgxTbOut &out) {
   typedef int mgx_i4 __attribute__((ext_vector_type(4)));
   constexpr int L = 2 * NS - 1;
   constexpr int LR = TY + 4 * NS;
@@ -779,7 +796,9 @@ __device__ __attribute__((noinline)) void mgx_tb_prefetch_wave(const T *__restri
     if (bl->big != 0u)
       mgx_block_exact_sum<T>(dst, g, tx0, min(tx0 + 127, g.n1), ty0, min(ty0 + TY - 1, g.n2), zc0, zc1, slo, shi, ovf);
   }
-  if (reduce & 3) mgx_block_commit<MGX_TB_WAVES(NW)>(0.0, slo, shi, ovf, reduce & 3, res, n_commit);
+  out.lo = slo;
+  out.hi = shi;
+  out.ovf = ovf;
 }
 
 template <typename T, int NS, int TY, int BOXES, int NW, int DF>
@@ -787,13 +806,13 @@ __device__ __forceinline__ void mgx_tb_tile(const T *__restrict__ src, T *__rest
                                             const MgxSweepParams<T> &p, const MgxBox *__restrict__ bx, const int nb,
                                             const int ntx, const int tile, const int zc0, const int zc1, const int reduce,
                                             u64 *__restrict__ res, T *__restrict__ lds, MgxBoxLds<T> *__restrict__ bl,
-                                            const int n_commit) {
+                                            const int n_commit, MgxTbOut &out) {
   const int tx = tile % ntx, ty = tile / ntx;
   const int tx0 = 1 + tx * 128, ty0 = 1 + ty * TY;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const bool halo = wave == NW;
   if (MGX_TB_PREFETCH && wave == NW + 1) {
-    mgx_tb_prefetch_wave<T, NS, TY, NW>(src, dst, g, tx0, ty0, zc0, zc1, reduce, res, bl, n_commit);
+    mgx_tb_prefetch_wave<T, NS, TY, NW>(src, dst, g, tx0, ty0, zc0, zc1, reduce, res, bl, n_commit, out);
     return;
   }
   constexpr int RW = (TY + 4 * NS) / NW;
@@ -814,7 +833,7 @@ __device__ __forceinline__ void mgx_tb_tile(const T *__restrict__ src, T *__rest
   // (see FREE above) staged rows ty0-2NS .. ty0+TY-1+2NS and columns tx0 .. tx0+127 all interior
   const bool free_rows = BOXES == 0 && ty0 - 2 * NS >= 1 && ty0 + TY - 1 + 2 * NS <= g.n2 && tx0 + 127 <= g.n1;
 #define MGX_TB_CALL(B_, P_, H_, F_, R0_) \
-  mgx_tb_body<T, NS, TY, B_, NW, DF, P_, H_, F_, R0_>(src, dst, g, p, bx, nb, tx0, ty0, zc0, zc1, reduce, res, lds, bl, n_commit, strip)
+  mgx_tb_body<T, NS, TY, B_, NW, DF, P_, H_, F_, R0_>(src, dst, g, p, bx, nb, tx0, ty0, zc0, zc1, reduce, res, lds, bl, n_commit, strip, out)
 #define MGX_TB_CALL_P(B_, H_, F_, R0_) { if (p0) MGX_TB_CALL(B_, 1, H_, F_, R0_); else MGX_TB_CALL(B_, 0, H_, F_, R0_); }
 #define MGX_TB_CALL_EDGE(R0_) { if (BOXES == 0 && free_rows) MGX_TB_CALL_P(0, false, true, (R0_)) else MGX_TB_CALL_P(BOXES, false, false, (R0_)) }
   if (halo) MGX_TB_CALL_P(BOXES, true, false, -1)
@@ -860,11 +879,13 @@ __global__ __launch_bounds__(MGX_TB_WAVES(NW) * 64) void k_tb_sweep(const T *__r
   if (entry < 0) return;
   const int cls = entry >> MGX_TILE_CLASS_SHIFT, tile = entry & ((1 << MGX_TILE_CLASS_SHIFT) - 1);
 #ifndef MGX_TB_LEAN_EXPERIMENT      /* (experiment builds: box-free levels only) */
-  if (cls == 2) mgx_tb_tile<T, NS, TY, 2, NW, DF>(src, dst, g, p, bx, nb, ntx, tile, zc0, zc1, reduce, res, lds, bl, n_commit);
-  else if (cls == 1) mgx_tb_tile<T, NS, TY, 1, NW, DF>(src, dst, g, p, bx, nb, ntx, tile, zc0, zc1, reduce, res, lds, bl, n_commit);
+  MgxTbOut out;
+  if (cls == 2) mgx_tb_tile<T, NS, TY, 2, NW, DF>(src, dst, g, p, bx, nb, ntx, tile, zc0, zc1, reduce, res, lds, bl, n_commit, out);
+  else if (cls == 1) mgx_tb_tile<T, NS, TY, 1, NW, DF>(src, dst, g, p, bx, nb, ntx, tile, zc0, zc1, reduce, res, lds, bl, n_commit, out);
   else
 #endif
-  mgx_tb_tile<T, NS, TY, 0, NW, DF>(src, dst, g, p, bx, nb, ntx, tile, zc0, zc1, reduce, res, lds, bl, n_commit);
+  mgx_tb_tile<T, NS, TY, 0, NW, DF>(src, dst, g, p, bx, nb, ntx, tile, zc0, zc1, reduce, res, lds, bl, n_commit, out);
+  if (reduce & 3) mgx_block_commit<MGX_TB_WAVES(NW)>(out.e2, out.lo, out.hi, out.ovf, reduce & 3, res, n_commit);
 }
 
 template <typename T, int NS, int TY, int NW, int DF>
