@@ -145,8 +145,10 @@ def one_transfer(ctx, rng, idx):
 
 def one_slab_case(ctx, rng, idx):
     """a level cut into two to four z slabs on one GPU (what the ranks of a multi-GPU run hold): every slab swept in
-    one launch or in edge + inner launches, two halo planes per side copied between the slabs after every sweep;
-    fields and reductions against the oracle's sweeps of the undivided level"""
+    one launch or in edge + inner launches, two halo planes per side copied between the slabs after every sweep; where
+    every slab has four planes, half of the cases keep four halo planes current and take passes of two sweeps (one
+    launch or edge + inner launches) with single sweeps in between; fields and reductions against the oracle's sweeps
+    of the undivided level"""
     import torch
     from multigrid_amd import slab
     dims = [3, 8, 17, 64, 65, 129, 140, 257]
@@ -180,11 +182,14 @@ def one_slab_case(ctx, rng, idx):
             lv.upload(V[z0:z0 + k + 2])
             slabs.append(lv)
 
+        depth = 4 if (kernel == 0 and min(k for _, k in parts) >= 4 and rng.integers(0, 2)) else 2
+        desc["depth"] = depth
+
         def exchange():
             ctx.sync()
             for lo, up in zip(slabs[:-1], slabs[1:]):
-                slab.device_plane_tensor(up, -1, 2).copy_(slab.device_plane_tensor(lo, lo.n3_local - 1, 2))
-                slab.device_plane_tensor(lo, lo.n3_local + 1, 2).copy_(slab.device_plane_tensor(up, 1, 2))
+                slab.device_plane_tensor(up, 1 - depth, depth).copy_(slab.device_plane_tensor(lo, lo.n3_local + 1 - depth, depth))
+                slab.device_plane_tensor(lo, lo.n3_local + 1, depth).copy_(slab.device_plane_tensor(up, 1, depth))
             torch.cuda.synchronize()
             for lv in slabs:
                 lv.halo_written()
@@ -192,15 +197,18 @@ def one_slab_case(ctx, rng, idx):
         exchange()
         for it in range(4):
             red = int(rng.choice([0, 1, 3, 3]))
+            two = depth == 4 and rng.integers(0, 3) > 0              # a pass of two sweeps, or a single sweep in between
+            if two:
+                orc.sweep(L, V, orc.ORDER_RB)
             e2 = orc.sweep(L, V, orc.ORDER_RB)
             s, big = orc.abs_sum_exact(L, V)
             rs = []
             for lv in slabs:
-                if rng.integers(0, 2):
-                    lv.sweep_part(lib.PART_EDGE, red)
-                    lv.sweep_part(lib.PART_INNER, red)
+                if rng.integers(0, 2) and not (depth == 4 and not two):
+                    lv.sweep_part(lib.PART_EDGE2 if two else lib.PART_EDGE, red)
+                    lv.sweep_part(lib.PART_INNER2 if two else lib.PART_INNER, red)
                 else:
-                    lv.sweep(1, red)
+                    lv.sweep(2 if two else 1, red)
                 if red:
                     rs.append(lv.result())
             exchange()
