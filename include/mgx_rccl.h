@@ -48,9 +48,20 @@ int mgx_comm_destroy(mgx_comm *comm);
  * such an exchange as well.  Replaces the boundary exchange of m_gs_br.F90:55-58. */
 int mgx_slab_exchange(mgx_level *lv, mgx_comm *comm, int planes);
 int mgx_slab_exchange_all(int n, mgx_level *const *lvs, mgx_comm *const *comms, int planes);
+/* The same exchange in two halves, for the overlap a split sweep is made for.  _begin: the planes leave once the
+ * context's stream has got to this call (the edge part before it has written them) and travel on a stream of the
+ * communicator's own; whatever the host enqueues on the context's stream next — MGX_PART_INNER / MGX_PART_INNER2 — runs
+ * beside them.  _end: the context's stream waits for the planes; call it before the next operation that reads halo
+ * planes (the next sweep, a restriction or prolongation).  mgx_slab_exchange is _begin followed by _end. */
+int mgx_slab_exchange_begin(mgx_level *lv, mgx_comm *comm, int planes);
+int mgx_slab_exchange_end(mgx_comm *comm);
+int mgx_slab_exchange_begin_all(int n, mgx_level *const *lvs, mgx_comm *const *comms, int planes);
+int mgx_slab_exchange_end_all(int n, mgx_comm *const *comms);
 /* After grid_setup of a level with a periodic C direction (t_mg.f90:553-583): ghost plane 0 of the first rank is plane
  * n3 of the last (c0_periodic), ghost plane n3+1 of the last rank is plane 1 of the first (c1_periodic).  Call it
- * before the first mgx_slab_exchange after a set-up, restriction or prolongation, then mgx_level_halo_written. */
+ * before the first mgx_slab_exchange after a set-up, restriction or prolongation; after that exchange call
+ * mgx_level_halo_written (planes the library did not write itself have changed: after a set-up, restriction or
+ * prolongation only, not after the exchange that follows a sweep). */
 int mgx_slab_periodic_ghosts(mgx_level *lv, mgx_comm *comm, int c0_periodic, int c1_periodic);
 int mgx_slab_periodic_ghosts_all(int n, mgx_level *const *lvs, mgx_comm *const *comms, int c0_periodic, int c1_periodic);
 

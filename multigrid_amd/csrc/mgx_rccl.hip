@@ -50,6 +50,10 @@ struct mgx_comm {
   hipStream_t stream = nullptr;
   uint64_t *d_rec = nullptr;   // W_WORDS words on the device
   uint64_t *h_rec = nullptr;   // pinned mirror
+  // halo planes travel on a stream of their own, between two events, so that what the host enqueues on the context's
+  // stream after mgx_slab_exchange_begin (the inner part of a split sweep) runs beside them
+  hipStream_t xstream = nullptr;
+  hipEvent_t ev_ready = nullptr, ev_done = nullptr;
 };
 
 extern "C" const char *mgx_comm_last_error(void) { return g_cerr; }
@@ -67,6 +71,9 @@ static int comm_buffers(mgx_comm *c) {
   HIPC_TRY(hipSetDevice(c->device));
   HIPC_TRY(hipMalloc((void **)&c->d_rec, W_WORDS * sizeof(uint64_t)));
   HIPC_TRY(hipHostMalloc((void **)&c->h_rec, W_WORDS * sizeof(uint64_t), hipHostMallocDefault));
+  HIPC_TRY(hipStreamCreateWithFlags(&c->xstream, hipStreamNonBlocking));
+  HIPC_TRY(hipEventCreateWithFlags(&c->ev_ready, hipEventDisableTiming));
+  HIPC_TRY(hipEventCreateWithFlags(&c->ev_done, hipEventDisableTiming));
   return MGX_OK;
 }
 
@@ -131,6 +138,9 @@ extern "C" int mgx_comm_destroy(mgx_comm *c) {
   if (c->nccl) (void)ncclCommDestroy(c->nccl);
   if (c->d_rec) (void)hipFree(c->d_rec);
   if (c->h_rec) (void)hipHostFree(c->h_rec);
+  if (c->ev_ready) (void)hipEventDestroy(c->ev_ready);
+  if (c->ev_done) (void)hipEventDestroy(c->ev_done);
+  if (c->xstream) (void)hipStreamDestroy(c->xstream);
   delete c;
   return MGX_OK;
 }
@@ -158,7 +168,7 @@ static int plane(mgx_level *lv, int z, int count, Plane *p) {
 
 // the transfers of one rank; to be called between ncclGroupStart and ncclGroupEnd.  Both sides of a link list the
 // transfers over it in the same order.
-static int post_halo(mgx_level *lv, mgx_comm *c, int d) {
+static int post_halo(mgx_level *lv, mgx_comm *c, int d, hipStream_t st) {
   int32_t n3 = 0;
   int r = check_pair("mgx_slab_exchange", lv, c, &n3);
   if (r != MGX_OK) return r;
@@ -168,15 +178,15 @@ static int post_halo(mgx_level *lv, mgx_comm *c, int d) {
   Plane p;
   if (c->rank > 0) {
     if ((r = plane(lv, 1, d, &p)) != MGX_OK) return r;
-    NCCL_TRY(ncclSend(p.ptr, p.bytes, ncclChar, c->rank - 1, c->nccl, c->stream));
+    NCCL_TRY(ncclSend(p.ptr, p.bytes, ncclChar, c->rank - 1, c->nccl, st));
     if ((r = plane(lv, 1 - d, d, &p)) != MGX_OK) return r;
-    NCCL_TRY(ncclRecv(p.ptr, p.bytes, ncclChar, c->rank - 1, c->nccl, c->stream));
+    NCCL_TRY(ncclRecv(p.ptr, p.bytes, ncclChar, c->rank - 1, c->nccl, st));
   }
   if (c->rank < c->world - 1) {
     if ((r = plane(lv, n3 + 1, d, &p)) != MGX_OK) return r;
-    NCCL_TRY(ncclRecv(p.ptr, p.bytes, ncclChar, c->rank + 1, c->nccl, c->stream));
+    NCCL_TRY(ncclRecv(p.ptr, p.bytes, ncclChar, c->rank + 1, c->nccl, st));
     if ((r = plane(lv, n3 + 1 - d, d, &p)) != MGX_OK) return r;
-    NCCL_TRY(ncclSend(p.ptr, p.bytes, ncclChar, c->rank + 1, c->nccl, c->stream));
+    NCCL_TRY(ncclSend(p.ptr, p.bytes, ncclChar, c->rank + 1, c->nccl, st));
   }
   return MGX_OK;
 }
@@ -223,14 +233,51 @@ static int grouped(int n, mgx_level *const *lvs, mgx_comm *const *comms, F post)
   return MGX_OK;
 }
 
+// the planes leave when the context's stream has got to this call, and travel on the communicator's own stream
+static int exchange_begin(int n, mgx_level *const *lvs, mgx_comm *const *comms, int planes) {
+  if (n < 1 || !lvs || !comms) return cfail(MGX_EINVAL, "mgx_slab_exchange: bad argument list");
+  for (int i = 0; i < n; ++i) {
+    mgx_comm *c = comms[i];
+    if (!c) return cfail(MGX_EINVAL, "mgx_slab_exchange: communicator %d is NULL", i);
+    HIPC_TRY(hipSetDevice(c->device));
+    HIPC_TRY(hipEventRecord(c->ev_ready, c->stream));
+    HIPC_TRY(hipStreamWaitEvent(c->xstream, c->ev_ready, 0));
+  }
+  int r = grouped(n, lvs, comms, [&](mgx_level *l, mgx_comm *c) { return post_halo(l, c, planes, c->xstream); });
+  for (int i = 0; i < n; ++i) {           // (also after a failed post: whatever was enqueued is waited for)
+    mgx_comm *c = comms[i];
+    if (hipSetDevice(c->device) != hipSuccess || hipEventRecord(c->ev_done, c->xstream) != hipSuccess)
+      if (r == MGX_OK) r = cfail(MGX_EHIP, "mgx_slab_exchange: hipEventRecord failed");
+  }
+  return r;
+}
+
+static int exchange_end(int n, mgx_comm *const *comms) {
+  if (n < 1 || !comms) return cfail(MGX_EINVAL, "mgx_slab_exchange_end: bad argument list");
+  for (int i = 0; i < n; ++i) {
+    mgx_comm *c = comms[i];
+    if (!c) return cfail(MGX_EINVAL, "mgx_slab_exchange_end: communicator %d is NULL", i);
+    HIPC_TRY(hipSetDevice(c->device));
+    HIPC_TRY(hipStreamWaitEvent(c->stream, c->ev_done, 0));
+  }
+  return MGX_OK;
+}
+
+extern "C" int mgx_slab_exchange_begin(mgx_level *lv, mgx_comm *comm, int planes) { return exchange_begin(1, &lv, &comm, planes); }
+extern "C" int mgx_slab_exchange_begin_all(int n, mgx_level *const *lvs, mgx_comm *const *comms, int planes) {
+  return exchange_begin(n, lvs, comms, planes);
+}
+extern "C" int mgx_slab_exchange_end(mgx_comm *comm) { return exchange_end(1, &comm); }
+extern "C" int mgx_slab_exchange_end_all(int n, mgx_comm *const *comms) { return exchange_end(n, comms); }
+
 extern "C" int mgx_slab_exchange(mgx_level *lv, mgx_comm *comm, int planes) {
-  if (comm && comm->world == 1 && (planes == 2 || planes == 4)) return MGX_OK;
-  return grouped(1, &lv, &comm, [&](mgx_level *l, mgx_comm *c) { return post_halo(l, c, planes); });
+  const int r = exchange_begin(1, &lv, &comm, planes);
+  return r != MGX_OK ? r : exchange_end(1, &comm);
 }
 
 extern "C" int mgx_slab_exchange_all(int n, mgx_level *const *lvs, mgx_comm *const *comms, int planes) {
-  if (n == 1) return mgx_slab_exchange(lvs ? lvs[0] : nullptr, comms ? comms[0] : nullptr, planes);
-  return grouped(n, lvs, comms, [&](mgx_level *l, mgx_comm *c) { return post_halo(l, c, planes); });
+  const int r = exchange_begin(n, lvs, comms, planes);
+  return r != MGX_OK ? r : exchange_end(n, comms);
 }
 
 extern "C" int mgx_slab_periodic_ghosts(mgx_level *lv, mgx_comm *comm, int c0, int c1) {

@@ -49,6 +49,30 @@ module mgx_rccl_c
        integer(c_int), value :: planes
        integer(c_int) :: rc
      end function mgx_slab_exchange_all
+     function mgx_slab_exchange_begin(lv, comm, planes) bind(C, name="mgx_slab_exchange_begin") result(rc)
+       import :: c_int, c_ptr
+       type(c_ptr), value :: lv, comm
+       integer(c_int), value :: planes
+       integer(c_int) :: rc
+     end function mgx_slab_exchange_begin
+     function mgx_slab_exchange_end(comm) bind(C, name="mgx_slab_exchange_end") result(rc)
+       import :: c_int, c_ptr
+       type(c_ptr), value :: comm
+       integer(c_int) :: rc
+     end function mgx_slab_exchange_end
+     function mgx_slab_exchange_begin_all(n, lvs, comms, planes) bind(C, name="mgx_slab_exchange_begin_all") result(rc)
+       import :: c_int, c_ptr
+       integer(c_int), value :: n
+       type(c_ptr), intent(in) :: lvs(*), comms(*)
+       integer(c_int), value :: planes
+       integer(c_int) :: rc
+     end function mgx_slab_exchange_begin_all
+     function mgx_slab_exchange_end_all(n, comms) bind(C, name="mgx_slab_exchange_end_all") result(rc)
+       import :: c_int, c_ptr
+       integer(c_int), value :: n
+       type(c_ptr), intent(in) :: comms(*)
+       integer(c_int) :: rc
+     end function mgx_slab_exchange_end_all
      function mgx_slab_periodic_ghosts(lv, comm, c0_periodic, c1_periodic) bind(C, name="mgx_slab_periodic_ghosts") result(rc)
        import :: c_int, c_ptr
        type(c_ptr), value :: lv, comm

@@ -1,8 +1,8 @@
 ! One level as z slabs over the GPUs of one process, exchange and reductions inside the library (mgx_rccl_c):
 !   slab_rccl <ngpu> <n> <sweeps> [<pairs>]
 ! An n^3 level, periodic in z (so that the far-rank ghost planes of the set-up are exercised), Dirichlet elsewhere,
-! two plate electrodes; every sweep is the edge part, the exchange, the inner part (the exchange travels beside the
-! bulk of the sweep).  With <pairs> = 1 two sweeps are taken per pass over the slabs and per exchange (four planes a
+! two plate electrodes; every sweep is the edge part, the start of the exchange, the inner part, the end of the
+! exchange (the planes travel on the communicator's own stream beside the bulk of the sweep).  With <pairs> = 1 two sweeps are taken per pass over the slabs and per exchange (four planes a
 ! side).  Prints max dV^2 and the exact sum after the last sweep: the numbers do not depend on <ngpu>.
 program slab_rccl
   use, intrinsic :: iso_c_binding
@@ -72,10 +72,11 @@ program slab_rccl
         do i = 1 , ngpu
            call mgx_check(mgx_level_sweep_part(lv(i), MGX_PART_EDGE2, MGX_RED_ERR + MGX_RED_SUM))
         end do
-        call comm_check(mgx_slab_exchange_all(int(ngpu, c_int), lv, comm, 4_c_int))
+        call comm_check(mgx_slab_exchange_begin_all(int(ngpu, c_int), lv, comm, 4_c_int))
         do i = 1 , ngpu
            call mgx_check(mgx_level_sweep_part(lv(i), MGX_PART_INNER2, MGX_RED_ERR + MGX_RED_SUM))
         end do
+        call comm_check(mgx_slab_exchange_end_all(int(ngpu, c_int), comm))
         s = s + 2
      else if ( pairs /= 0 ) then
         ! an odd single sweep between passes of two: its edge part completes two planes a side, four are exchanged,
@@ -89,10 +90,11 @@ program slab_rccl
         do i = 1 , ngpu
            call mgx_check(mgx_level_sweep_part(lv(i), MGX_PART_EDGE, MGX_RED_ERR + MGX_RED_SUM))
         end do
-        call comm_check(mgx_slab_exchange_all(int(ngpu, c_int), lv, comm, 2_c_int))
+        call comm_check(mgx_slab_exchange_begin_all(int(ngpu, c_int), lv, comm, 2_c_int))
         do i = 1 , ngpu
            call mgx_check(mgx_level_sweep_part(lv(i), MGX_PART_INNER, MGX_RED_ERR + MGX_RED_SUM))
         end do
+        call comm_check(mgx_slab_exchange_end_all(int(ngpu, c_int), comm))
         s = s + 1
      end if
   end do

@@ -213,6 +213,25 @@ def grid_BC(grid: MgGrid, BC: int, plane: Optional[int] = None) -> None:
 # how grid_add_box finds the cells of a box: "auto" = per-axis arithmetic on the host for orthogonal cells, the
 # device kernel for skewed ones; "device" = the device kernel always
 BOX_PLACEMENT = os.environ.get("MGX_BOX_PLACEMENT", "auto")
+PLACEMENT_CONTEXT = None     # lib.Context that places boxes on skewed cells (None: lib.shared_context() of the rank's device)
+
+
+class placement_context:
+    """`with grid.placement_context(ctx): top = mgio.iomg_read(...)`: boxes on skewed cells are placed through `ctx`
+    (its device, its stream) instead of a context the package opens by itself"""
+
+    def __init__(self, ctx):
+        self.ctx, self.old = ctx, None
+
+    def __enter__(self):
+        global PLACEMENT_CONTEXT
+        self.old, PLACEMENT_CONTEXT = PLACEMENT_CONTEXT, self.ctx
+        return self.ctx
+
+    def __exit__(self, *exc):
+        global PLACEMENT_CONTEXT
+        PLACEMENT_CONTEXT = self.old
+        return False
 
 
 def grid_add_box(grid: MgGrid, llc, box_cell, val: float, rho: float, constant: bool, recurse: Optional[bool] = None) -> None:
@@ -262,10 +281,12 @@ def grid_add_box(grid: MgGrid, llc, box_cell, val: float, rho: float, constant: 
                             lo[i] = min(lo[i], v + 1)
                             hi[i] = max(hi[i], v + 1)
     else:
-        # skewed cells: the reference's loop over every cell (t_mg.f90:363-390), run on the GPU (mgx_box_place);
-        # there is no host form of it here
+        # skewed cells: the reference's loop over every cell (t_mg.f90:363-390), run on the GPU (mgx_box_place).
+        # There is no host form of it on purpose: this package has no CPU fallback for anything the library does.
+        # The context: the one the caller named (placement_context), else one on the rank's own device.
         from . import lib
-        pl = lib.shared_context().box_place((n1, n2, n3), grid.dL, grid.offset, llc, box_cell)
+        ctx = PLACEMENT_CONTEXT if PLACEMENT_CONTEXT is not None else lib.shared_context()
+        pl = ctx.box_place((n1, n2, n3), grid.dL, grid.offset, llc, box_cell)
         lo[:] = pl[0::2]
         hi[:] = np.where(pl[0::2] == HUGE_INT, 0, pl[1::2])
 

@@ -109,12 +109,35 @@ def load():
 _shared = {}
 
 
-def shared_context(device: int = 0) -> "Context":
-    """a context (own stream) kept for the life of the process, for host-side helpers that need the device before
-    any solver exists (box placement while an input file is read)"""
+def default_device() -> int:
+    """the device of host-side helpers that are not handed a context: MGX_DEVICE, else the rank's own device in a
+    one-process-per-GPU job (LOCAL_RANK), else 0"""
+    for name in ("MGX_DEVICE", "LOCAL_RANK"):
+        v = os.environ.get(name)
+        if v is not None and v.strip().lstrip("-").isdigit():
+            return max(0, int(v))
+    return 0
+
+
+def shared_context(device: Optional[int] = None) -> "Context":
+    """a context (own stream) for host-side helpers that need the device before any solver exists (box placement on
+    skewed cells while an input file is read): one per device, closed when the process ends"""
+    device = default_device() if device is None else int(device)
     if device not in _shared:
+        if not _shared:
+            import atexit
+            atexit.register(close_shared_contexts)
         _shared[device] = Context(device)
     return _shared[device]
+
+
+def close_shared_contexts():
+    for ctx in list(_shared.values()):
+        try:
+            ctx.close()
+        except Exception:
+            pass
+    _shared.clear()
 
 
 def _ck(rc):

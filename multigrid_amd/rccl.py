@@ -15,7 +15,8 @@ COMM_ID_BYTES = 128
 
 SYMBOLS = [
     "mgx_comm_last_error", "mgx_comm_unique_id", "mgx_comm_create", "mgx_comm_create_all", "mgx_comm_destroy",
-    "mgx_slab_exchange", "mgx_slab_exchange_all", "mgx_slab_periodic_ghosts", "mgx_slab_periodic_ghosts_all",
+    "mgx_slab_exchange", "mgx_slab_exchange_all", "mgx_slab_exchange_begin", "mgx_slab_exchange_end",
+    "mgx_slab_exchange_begin_all", "mgx_slab_exchange_end_all", "mgx_slab_periodic_ghosts", "mgx_slab_periodic_ghosts_all",
     "mgx_allreduce_result", "mgx_allreduce_result_all",
 ]
 
@@ -37,6 +38,8 @@ def load():
         "mgx_comm_unique_id": [vp], "mgx_comm_create": [vp, C.c_int, C.c_int, vp, pvp],
         "mgx_comm_create_all": [C.c_int, pvp, pvp], "mgx_comm_destroy": [vp],
         "mgx_slab_exchange": [vp, vp, C.c_int], "mgx_slab_exchange_all": [C.c_int, pvp, pvp, C.c_int],
+        "mgx_slab_exchange_begin": [vp, vp, C.c_int], "mgx_slab_exchange_end": [vp],
+        "mgx_slab_exchange_begin_all": [C.c_int, pvp, pvp, C.c_int], "mgx_slab_exchange_end_all": [C.c_int, pvp],
         "mgx_slab_periodic_ghosts": [vp, vp, C.c_int, C.c_int],
         "mgx_slab_periodic_ghosts_all": [C.c_int, pvp, pvp, C.c_int, C.c_int],
         "mgx_allreduce_result": [vp, vp, pdbl, pdbl, pu64],
@@ -83,6 +86,12 @@ class Comm:
 
     def exchange(self, lv, planes: int = 2):
         _ck(load().mgx_slab_exchange(lv.h, self.h, int(planes)))
+
+    def exchange_begin(self, lv, planes: int = 2):
+        _ck(load().mgx_slab_exchange_begin(lv.h, self.h, int(planes)))
+
+    def exchange_end(self):
+        _ck(load().mgx_slab_exchange_end(self.h))
 
     def periodic_ghosts(self, lv, c0: bool, c1: bool):
         _ck(load().mgx_slab_periodic_ghosts(lv.h, self.h, int(c0), int(c1)))

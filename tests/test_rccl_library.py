@@ -48,7 +48,14 @@ def test_single_rank_communicator_reduces_and_wraps():
         (comm,) = rccl.Comm.create_all([ctx])
         for _ in range(3):
             lv.sweep(1, lib.RED_ERR | lib.RED_SUM)
-            comm.exchange(lv)                      # one rank: nothing to do
+            comm.exchange(lv)                      # one rank: no planes travel; the streams still meet
+        for planes in (2, 4):                      # a split sweep with the exchange around its inner part
+            lv.sweep_part(lib.PART_EDGE, lib.RED_ERR | lib.RED_SUM)
+            comm.exchange_begin(lv, planes)
+            lv.sweep_part(lib.PART_INNER, lib.RED_ERR | lib.RED_SUM)
+            comm.exchange_end()
+        with pytest.raises(lib.MgxError):
+            comm.exchange_begin(lv, 3)
         want = lv.result()
         assert comm.allreduce_result(lv) == want and want[1] > 0
         V = lv.download()                          # (n3+2 [+ halo planes], n2+2, n1+2) ghosted
