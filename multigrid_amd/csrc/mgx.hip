@@ -936,14 +936,14 @@ extern "C" int mgx_level_half_sweep(mgx_level *lv, int parity, int32_t zlo, int3
 // that voids the sweeps still queued behind it.  The host reads one small record per batch.
 #define MGX_SOLVE_BATCH 24
 #define MGX_SOLVE_LOOP_BATCH 1024   /* sweeps per launch of the one-launch loop (k_small_solve) */
-#define MGX_SMALL_MAX_CELLS 600000   /* levels up to this many cells take it: beyond, a sweep is bytes, not latency */
 template <typename T>
 static int do_solve(mgx_level *lv, double tol_level, double nr, double old_sum, long long max_sweeps, long long hist_cap,
                     double *hist, long long *nsweeps, int *status) {
   mgx_ctx *c = C(lv);
   const MgxGeom &g = lv->g;
   hipStream_t st = c->stream;
-  constexpr size_t state_bytes = sizeof(MgxSolveState) + sizeof(double) * 3 * MGX_SOLVE_LOOP_BATCH;
+  constexpr size_t hist_bytes = sizeof(MgxSolveState) + sizeof(double) * 3 * MGX_SOLVE_LOOP_BATCH;
+  constexpr size_t state_bytes = hist_bytes + sizeof(u64) * 2 * MGX_SMALL_MAXBLOCKS * MGX_SMALL_SLOT_WORDS;   // + the slots of k_small_solve
   static_assert(MGX_SOLVE_LOOP_BATCH >= MGX_SOLVE_BATCH, "history buffer");
   if (!lv->d_solve) HIP_TRY(hipMalloc((void **)&lv->d_solve, state_bytes));
   if (!c->h_solve) HIP_TRY(hipHostMalloc((void **)&c->h_solve, state_bytes, hipHostMallocDefault));
@@ -968,14 +968,15 @@ static int do_solve(mgx_level *lv, double tol_level, double nr, double old_sum, 
       // every block must be on the device while the others wait for it: at most one per compute unit
       int cus = 0;
       HIP_TRY(hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, c->device));
-      const long long ncol = (long long)((g.n1 + 1) / 2) * g.n2 * g.n3;
-      const long long blocks = std::min<long long>(cus, (ncol + 511) / 512);
-      if (ncol > MGX_SMALL_MAX_CELLS / 2 || blocks * 256 * MGX_SMALL_CPT < ncol || g.n1 > 1000 || g.n2 > 1000 || g.n3 > 1000) {
+      const long long npair = (long long)((g.n1 + 1) / 2) * g.n2 * g.n3;
+      const long long blocks = std::min<long long>(std::min(cus, MGX_SMALL_MAXBLOCKS), (npair + 255) / 256);
+      if (blocks < 1 || blocks * 256 * MGX_SMALL_CPT < npair || g.n1 > 1000 || g.n2 > 1000 || g.n3 > 1000) {
         one_launch = false;
         continue;
       }
-      hipLaunchKernelGGL((k_small_solve<T>), dim3((unsigned)blocks), dim3(256), 0, st, (T *)lv->buf[cur0], g, p, lv->d_boxes,
-                         lv->nbox, lv->d_res, lv->d_solve, d_hist, MGX_SOLVE_LOOP_BATCH, tol_level, nr, batch);
+      u64 *slots = reinterpret_cast<u64 *>(reinterpret_cast<char *>(lv->d_solve) + hist_bytes);
+      hipLaunchKernelGGL((k_small_solve<T>), dim3((unsigned)blocks), dim3(256), 0, st, (T *)lv->buf[cur0], (T *)lv->buf[1 - cur0], g, p,
+                         lv->d_boxes, lv->nbox, lv->d_res, lv->d_solve, d_hist, slots, MGX_SOLVE_LOOP_BATCH, tol_level, nr, batch);
     }
     for (int j = 0; j < batch && !one_launch; ++j) {
       const int a = cur0 ^ (j & 1);
@@ -995,7 +996,7 @@ static int do_solve(mgx_level *lv, double tol_level, double nr, double old_sum, 
       if (done + i < hist_cap)
         for (int k = 0; k < 3; ++k) hist[3 * (done + i) + k] = hh[3 * i + k];
     done += cnt;
-    if (!one_launch) lv->cur = cur0 ^ (cnt & 1);            // the sweeps behind the flag left the buffers alone
+    lv->cur = cur0 ^ (cnt & 1);                             // the sweeps behind the flag left the buffers alone
     if (one_launch && (hs->gen >> 28) == 3u)
       return fail(MGX_EHIP, "mgx_level_solve: a block of the one-launch loop gave up waiting for the others (level %d): "
                   "the field of this level is not valid", lv->layer);

@@ -131,11 +131,12 @@ __device__ MGX_TB_BODY_ATTR void mgx_tb_body(const T *__restrict__ src_, T *__re
   const MgxBox *__restrict__ bx = MGX_TB_UNI(bx_);
   const int nb = MGX_TB_UNI(nb_), tx0 = MGX_TB_UNI(tx0_), ty0 = MGX_TB_UNI(ty0_), zc0 = MGX_TB_UNI(zc0_), zc1 = MGX_TB_UNI(zc1_);
 #ifdef MGX_TB_RED_CONST
-  const int reduce = MGX_TB_RED_CONST | (MGX_TB_UNI(reduce_) & ~3), n_commit = MGX_TB_UNI(n_commit_);
+  const int reduce = MGX_TB_RED_CONST | (MGX_TB_UNI(reduce_) & ~3);
 #else
-  const int reduce = MGX_TB_UNI(reduce_), n_commit = MGX_TB_UNI(n_commit_);
+  const int reduce = MGX_TB_UNI(reduce_);
 #endif
-  u64 *__restrict__ res = MGX_TB_UNI(res_);
+  (void)n_commit_;                                  // (the kernel commits for the block: see MgxTbOut)
+  (void)res_;
   typedef typename MgxVec2<T>::type V2;
   constexpr int TXP = 64;
   constexpr int HP = NS;                   // halo pairs on either side of a row
@@ -150,7 +151,8 @@ __device__ MGX_TB_BODY_ATTR void mgx_tb_body(const T *__restrict__ src_, T *__re
   static_assert(LR % 2 == 0 && (LR / 2) * 2 * HP <= 64, "the halo pairs of two rows per lane must fit one wave");
   static_assert(DF == 1, "one plane in flight");
   auto A = [&](int stage, int buf, int i) __attribute__((always_inline)) -> T & { return lds[(stage * 2 + buf) * PL + i]; };
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63;
+  [[maybe_unused]] const int wave = threadIdx.x >> 6;     // (named by the time-stamp build only)
 
   // ---- items: branch-free per item; what must not be touched is masked by value selects, its loads go to the
   // first element of the plane and its LDS writes to the guard row; only the global stores are predicated ----
@@ -751,8 +753,9 @@ __device__ __attribute__((noinline)) void mgx_tb_prefetch_wave(const T *__restri
   g.n1 = mgx_uni(g_.n1); g.n2 = mgx_uni(g_.n2); g.n3 = mgx_uni(g_.n3); g.n3g = mgx_uni(g_.n3g); g.z0 = mgx_uni(g_.z0);
   g.px = mgx_uni(g_.px); g.py = mgx_uni(g_.py); g.pz = mgx_uni(g_.pz); g.front = mgx_uni(g_.front);
   const int tx0 = mgx_uni(tx0_), ty0 = mgx_uni(ty0_), zc0 = mgx_uni(zc0_), zc1 = mgx_uni(zc1_);
-  const int reduce = mgx_uni(reduce_), n_commit = mgx_uni(n_commit_);
-  u64 *__restrict__ res = mgx_uni(res_);
+  const int reduce = mgx_uni(reduce_);
+  (void)n_commit_;
+  (void)res_;
   const int lane = threadIdx.x & 63;
   const unsigned plane_bytes = (unsigned)((g.pz + g.front) * (long long)sizeof(T));
   unsigned off[NLOAD];                           // byte offset of "my" lines inside a plane; out of range = none
