@@ -36,15 +36,8 @@
 
 #include "mgx_fused.hpp"
 
-// waves of a block: NW row waves, the wave of the x-halo pairs, and (MGX_TB_PREFETCH) one that only touches the
-// planes ahead (mgx_tb_prefetch_wave)
-#ifndef MGX_TB_PREFETCH
-#define MGX_TB_PREFETCH 0
-#endif
-#ifndef MGX_TB_PREFETCH_AHEAD
-#define MGX_TB_PREFETCH_AHEAD 2                  /* planes ahead of the plane the working waves load in the same step */
-#endif
-#define MGX_TB_WAVES(NW) ((NW) + 1 + (MGX_TB_PREFETCH ? 1 : 0))
+// waves of a block: NW row waves and the wave of the x-halo pairs
+#define MGX_TB_WAVES(NW) ((NW) + 1)
 #ifndef MGX_TB_EDGE_STRIPS
 #define MGX_TB_EDGE_STRIPS 1                     /* the first and the last strip of rows leave out the rows a stage does not need */
 #endif
@@ -326,9 +319,6 @@ __device__ MGX_TB_BODY_ATTR void mgx_tb_body(const T *__restrict__ src_, T *__re
 #ifndef MGX_TB_SHIFT2
 #define MGX_TB_SHIFT2 0                          /* the window moves two planes every second step (1) or one plane every step (0) */
 #endif
-#ifndef MGX_TB_FAST
-#define MGX_TB_FAST 0                            /* FREE row waves run the mask-free step where they can */
-#endif
 #if MGX_TB_SHIFT2
 #define MGX_PW(i) W[(i) + 1 - U]                  /* plane k + 1 - i at unroll position U */
 #define MGX_FETCH_INTO_W0 (U == 0)
@@ -340,13 +330,6 @@ __device__ MGX_TB_BODY_ATTR void mgx_tb_body(const T *__restrict__ src_, T *__re
 #define MGX_SHIFT_NOW true
 #define MGX_SHIFT_BY 1
 #endif
-  // ---- the mask-free step (FAST): one block of straight-line code ----
-  // A FREE row wave runs it on the steps on which every stage works inside its own z range and inside the level
-  // (kf_lo .. kf_hi below): no plane-range tests, no flag tests, the stores through a buffer descriptor of the plane
-  // whose range check drops the pairs that are not the tile's own (offset beyond the plane), the reductions without
-  // selects (one max |dV| per item, looked at per row at the end; rows that do not count get their |V| masked to a
-  // value that adds exactly nothing by one AND with a wave-uniform mask).  Nothing in it depends on a condition, so
-  // the compiler is free to issue a stage's LDS reads under the arithmetic of the stage before.
 #ifdef MGX_TB_STAMPS      /* experiment builds: where the cycles of a step go (printed by one block) */
   unsigned long long stamp_acc[6] = {0, 0, 0, 0, 0, 0}, stamp_prev = 0;
 #define MGX_STAMP(i) { __builtin_amdgcn_sched_barrier(0); unsigned long long t_; asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); \
@@ -354,141 +337,6 @@ __device__ MGX_TB_BODY_ATTR void mgx_tb_body(const T *__restrict__ src_, T *__re
 #else
 #define MGX_STAMP(i)
 #endif
-  T errj[R];
-  unsigned smask[R];                             // 0x7fffffff for the rows of the tile proper, 0 for the others (uniform)
-  unsigned stoff[R];                             // byte offset of the pair inside its plane if it is stored, else out of range
-#pragma unroll
-  for (int j = 0; j < R; ++j) {
-    errj[j] = (T)0;
-    smask[j] = 0u;
-    stoff[j] = st[j] ? gob[j] : 0x80000000u;
-  }
-  const unsigned plane_bytes = (unsigned)((g.pz + g.front) * (long long)sizeof(T));   // < 2^31 (mgx_fused_supported)
-  typedef unsigned mgx_u4 __attribute__((ext_vector_type(4)));
-  typedef unsigned mgx_u2 __attribute__((ext_vector_type(2)));
-  auto fast_step = [&](auto Uc, auto REDc, const int k) __attribute__((always_inline)) {
-    constexpr int U = decltype(Uc)::value;
-    constexpr int RED = decltype(REDc)::value;
-    MGX_STAMP(-1)
-#ifndef MGX_TB_FAST_MEM
-#define MGX_TB_FAST_MEM 2                        /* experiment builds: 0 flat loads and stores, 1 buffer loads, 2 buffer loads and stores */
-#endif
-    if constexpr (MGX_TB_FAST_MEM == 0) {
-      if constexpr (MGX_FETCH_INTO_W0) fetch(W[0], k + 2); else fetch(FF, k + 2);
-    } else {                                     // plane k + 2 into the set that is free at this position
-      int z = k + 2;
-#ifdef MGX_TB_ABLATE_FIXEDPLANE     /* timing experiment: every step loads the same plane (cache hits) */
-      z = zc0;
-#endif
-      z = z < zmin ? zmin : z > zmax ? zmax : z;
-      const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
-          const_cast<T *>(src + pzl * (z + 1)), 0, (int)plane_bytes, 0x00020000);
-#pragma unroll
-      for (int j = 0; j < R; ++j) {
-        V2 t_;
-        if constexpr (sizeof(T) == 8) {
-          const mgx_u4 r_ = __builtin_amdgcn_raw_buffer_load_b128(rs, (int)gob[j], 0, 0);
-          t_.x = __hiloint2double((int)r_.y, (int)r_.x);
-          t_.y = __hiloint2double((int)r_.w, (int)r_.z);
-        } else {
-          const mgx_u2 r_ = __builtin_amdgcn_raw_buffer_load_b64(rs, (int)gob[j], 0, 0);
-          t_.x = __uint_as_float(r_.x);
-          t_.y = __uint_as_float(r_.y);
-        }
-        if constexpr (MGX_FETCH_INTO_W0) W[0][j] = t_; else FF[j] = t_;
-      }
-    }
-    auto stage = [&](auto Sc) __attribute__((always_inline)) {
-      constexpr int S = decltype(Sc)::value;
-      T other[R];
-#pragma unroll
-      for (int j = 0; j < R; ++j) other[j] = A(S, U, li[j] + (2 * MGX_TBQ(U, j) - 1));
-      const T vylo = A(S, U, li[0] - LP), vyhi = A(S, U, li[R - 1] + LP);
-#pragma unroll
-      for (int j = 0; j < R; ++j) {
-        const int q = MGX_TBQ(U, j);
-        const T vc = MGX_CMP(MGX_PW(S + 1)[j], q), partner = MGX_CMP(MGX_PW(S + 1)[j], 1 - q);
-        const T zhi = MGX_CMP(MGX_PW(S)[j], q);
-        T zlo;
-        if constexpr (S == L) zlo = below[j]; else zlo = MGX_CMP(MGX_PW(S + 2)[j], q);
-        // the rows of a lane are neighbours: the cells at y - 1 and y + 1 (the other colour, the same position in
-        // their pairs) sit in the lane's own registers, except under the first and above the last row
-        const T vym = j == 0 ? vylo : MGX_CMP(MGX_PW(S + 1)[j > 0 ? j - 1 : 0], q);
-        const T vyp = j == R - 1 ? vyhi : MGX_CMP(MGX_PW(S + 1)[j < R - 1 ? j + 1 : R - 1], q);
-        const T vv = p.s1 * vc + p.s2 * mgx_avg_uniform<T>(partner, other[j], vym, vyp, zlo, zhi, p.w);
-        if (q) MGX_PW(S + 1)[j].y = vv; else MGX_PW(S + 1)[j].x = vv;
-        if constexpr (S >= L - 1 && (RED & 1) != 0) errj[j] = mgx_max_abs(errj[j], vv - vc);
-        if constexpr (S >= L - 1 && (RED & 2) != 0) {
-          const double v_ = (double)vv;
-          const unsigned h_ = (unsigned)__double2hiint(v_) & smask[j];
-          const unsigned t_ = sizeof(T) == 8 ? h_ : (mgx_abs_top(vv) & smask[j]);
-          topmax = t_ > topmax ? t_ : topmax;
-          mgx_fast_sum_add(fh, fl2, __hiloint2double((int)h_, __double2loint(v_)));
-        }
-      }
-      if constexpr (S == L && MGX_TB_FAST_MEM < 2) {
-        char *pb = reinterpret_cast<char *>(dst + pzl * (k - L + 1));
-#pragma unroll
-        for (int j = 0; j < R; ++j)
-          if (st[j]) {
-            typedef T nv2 __attribute__((ext_vector_type(2)));
-            nv2 o_;
-            o_.x = MGX_PW(L + 1)[j].x;
-            o_.y = MGX_PW(L + 1)[j].y;
-            __builtin_nontemporal_store(o_, reinterpret_cast<nv2 *>(pb + gob[j]));
-          }
-      }
-      if constexpr (S == L && MGX_TB_FAST_MEM == 2) {
-        const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(dst + pzl * (k - L + 1), 0, (int)plane_bytes,
-                                                                            0x00020000);
-#pragma unroll
-        for (int j = 0; j < R; ++j) {
-          if constexpr (sizeof(T) == 8) {
-            mgx_u4 o_;
-            o_.x = (unsigned)__double2loint(MGX_PW(L + 1)[j].x); o_.y = (unsigned)__double2hiint(MGX_PW(L + 1)[j].x);
-            o_.z = (unsigned)__double2loint(MGX_PW(L + 1)[j].y); o_.w = (unsigned)__double2hiint(MGX_PW(L + 1)[j].y);
-            __builtin_amdgcn_raw_buffer_store_b128(o_, rd, (int)stoff[j], 0, 2 /* nt */);
-          } else {
-            mgx_u2 o_;
-            o_.x = __float_as_uint(MGX_PW(L + 1)[j].x); o_.y = __float_as_uint(MGX_PW(L + 1)[j].y);
-            __builtin_amdgcn_raw_buffer_store_b64(o_, rd, (int)stoff[j], 0, 2 /* nt */);
-          }
-        }
-      }
-    };
-    stage(std::integral_constant<int, 0>{});
-    stage(std::integral_constant<int, 1>{});
-    if constexpr (NS > 1) {
-      stage(std::integral_constant<int, 2>{});
-      stage(std::integral_constant<int, 3>{});
-    }
-    MGX_STAMP(0)
-#pragma unroll
-    for (int j = 0; j < R; ++j) {
-      const int q = MGX_TBQ(U, j);
-#pragma unroll
-      for (int sgl = 0; sgl <= L; ++sgl) A(sgl, 1 - U, li[j]) = MGX_CMP(MGX_PW(sgl)[j], q);
-      below[j] = MGX_CMP(MGX_PW(L + 1)[j], 1 - q);
-    }
-    MGX_STAMP(1)
-    MGX_TB_SYNC();
-    MGX_STAMP(2)
-#ifdef MGX_TB_STAMPS
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    MGX_STAMP(3)
-#endif
-    if constexpr (MGX_SHIFT_NOW) {
-#pragma unroll
-      for (int i = NP; i >= MGX_SHIFT_BY; --i)
-#pragma unroll
-        for (int j = 0; j < R; ++j) W[i][j] = W[i - MGX_SHIFT_BY][j];
-      if constexpr (MGX_SHIFT_BY == 2) {
-#pragma unroll
-        for (int j = 0; j < R; ++j) W[1][j] = FF[j];
-      }
-    }
-  };
-
   // one step: U = unroll position (parity of k - k0)
   auto step = [&](auto Uc, const int k) __attribute__((always_inline)) {
     constexpr int U = decltype(Uc)::value;
@@ -667,38 +515,11 @@ __device__ MGX_TB_BODY_ATTR void mgx_tb_body(const T *__restrict__ src_, T *__re
   static_assert(2 * 2 * R * MGX_FLUSH_GROUPS <= MGX_FAST_SUM_CELLS, "partial sums must stay exact between two flushes");
   int turns = 0;
   const int kend = zc1 + L;
-  // steps on which a FREE row wave may run the mask-free step: past the 2 L steps in which the stages start one after
-  // the other, before the last step (its stage L - 1 works on plane zc1 + 1, which is not the tile's own), and with
-  // stage 0 (plane k) inside the level
-  constexpr bool HAS_FAST = MGX_TB_FAST != 0 && FREE && !HALO && BOXES == 0 && ROW0 < 0;
-  const int kf_lo = k0 + 2 * L, kf_hi = min(kend - 1, g.n3g - g.z0);
-  if constexpr (HAS_FAST) {
-#pragma unroll
-    for (int j = 0; j < R; ++j) smask[j] = rowin[j] ? 0x7fffffffu : 0u;
-  }
-  auto run = [&](auto REDc) __attribute__((always_inline)) {
 #pragma clang loop unroll(disable)
-    for (int kb = k0; kb <= kend; kb += 2) {
-      if (HAS_FAST && kb >= kf_lo && kb + 1 <= kf_hi) {
-        if constexpr (HAS_FAST) {
-          fast_step(std::integral_constant<int, 0>{}, REDc, kb);
-          fast_step(std::integral_constant<int, 1>{}, REDc, kb + 1);
-        }
-      } else {
-        step(std::integral_constant<int, 0>{}, kb);
-        if (kb + 1 <= kend) step(std::integral_constant<int, 1>{}, kb + 1);
-      }
-      if (!HALO && (reduce & 2) && (++turns % MGX_FLUSH_GROUPS) == 0) mgx_fast_sum_flush(fh, fl2, slo, shi);
-    }
-  };
-  if constexpr (HAS_FAST) {
-    if ((reduce & 3) == 0) run(std::integral_constant<int, 0>{});
-    else if ((reduce & 3) == 1) run(std::integral_constant<int, 1>{});
-    else run(std::integral_constant<int, 3>{});
-#pragma unroll
-    for (int j = 0; j < R; ++j) err = mgx_max_abs(err, rowin[j] ? errj[j] : (T)0);
-  } else {
-    run(std::integral_constant<int, 0>{});
+  for (int kb = k0; kb <= kend; kb += 2) {
+    step(std::integral_constant<int, 0>{}, kb);
+    if (kb + 1 <= kend) step(std::integral_constant<int, 1>{}, kb + 1);
+    if (!HALO && (reduce & 2) && (++turns % MGX_FLUSH_GROUPS) == 0) mgx_fast_sum_flush(fh, fl2, slo, shi);
   }
   if (!HALO && (reduce & 2)) mgx_fast_sum_flush(fh, fl2, slo, shi);
 #ifdef MGX_TB_STAMPS
@@ -729,81 +550,6 @@ __device__ MGX_TB_BODY_ATTR void mgx_tb_body(const T *__restrict__ src_, T *__re
   out.ovf = ovf;
 }
 
-// ---- the wave that loads nothing for itself ----
-// A wave waits for the plane it loaded at the start of a step before the step ends (the window moves on), so a step
-// cannot take less than one trip to memory; once the arithmetic of a step is shorter than that trip, the trip paces
-// the whole block.  One more wave per block therefore touches every 128-byte line of the tile's plane a few steps
-// before the others load it, with loads whose results nobody waits for: the planes the working waves ask for are in
-// the L2 cache by then.  It takes part in every barrier and in the reductions' hand-off (with nothing to add).
-
-template <typename T, int NS, int TY, int NW>
-__device__ __attribute__((noinline)) void mgx_tb_prefetch_wave(const T *__restrict__ src_, T *__restrict__ dst_, const MgxGeom g_,
-                                                               const int tx0_, const int ty0_, const int zc0_, const int zc1_,
-                                                               const int reduce_, u64 *__restrict__ res_,
-                                                               MgxBoxLds<T> *__restrict__ bl, const int n_commit_, MgxTbOut &out) {
-  typedef int mgx_i4 __attribute__((ext_vector_type(4)));
-  constexpr int L = 2 * NS - 1;
-  constexpr int LR = TY + 4 * NS;
-  constexpr int ROW_BYTES = (64 + 2 * NS) * 2 * (int)sizeof(T);             // staged pairs of a row
-  constexpr int LINES = (ROW_BYTES + 127 + 127) / 128;                      // lines a row can touch (any alignment)
-  constexpr int NLOAD = (LR * LINES + 63) / 64;
-  const T *__restrict__ src = mgx_uni(src_);
-  T *__restrict__ dst = mgx_uni(dst_);
-  MgxGeom g;
-  g.n1 = mgx_uni(g_.n1); g.n2 = mgx_uni(g_.n2); g.n3 = mgx_uni(g_.n3); g.n3g = mgx_uni(g_.n3g); g.z0 = mgx_uni(g_.z0);
-  g.px = mgx_uni(g_.px); g.py = mgx_uni(g_.py); g.pz = mgx_uni(g_.pz); g.front = mgx_uni(g_.front);
-  const int tx0 = mgx_uni(tx0_), ty0 = mgx_uni(ty0_), zc0 = mgx_uni(zc0_), zc1 = mgx_uni(zc1_);
-  const int reduce = mgx_uni(reduce_);
-  (void)n_commit_;
-  (void)res_;
-  const int lane = threadIdx.x & 63;
-  const unsigned plane_bytes = (unsigned)((g.pz + g.front) * (long long)sizeof(T));
-  unsigned off[NLOAD];                           // byte offset of "my" lines inside a plane; out of range = none
-#pragma unroll
-  for (int i = 0; i < NLOAD; ++i) {
-    const int idx = lane + 64 * i, r = idx / LINES, ln = idx % LINES;
-    const int y = ty0 - 2 * NS + r;
-    const long long row0 = (g.front + (long long)(tx0 - 2 * NS - 1) + (long long)g.px * y) * (long long)sizeof(T);
-    const long long b = (row0 & ~127ll) + 128ll * ln;
-    const bool ok = r < LR && y >= 0 && y <= g.n2 + 1 && b >= 0 && b < row0 + ROW_BYTES && b + 4 <= (long long)plane_bytes;
-    off[i] = ok ? (unsigned)b : 0x80000000u;
-  }
-  const int k0 = zc0 - L, kend = zc1 + L;
-  auto touch = [&](int z) __attribute__((always_inline)) {
-    if (z < (g.n3 != g.n3g ? -3 : -1) || z > (g.n3 != g.n3g ? g.n3 + 4 : g.n3 + 2)) return;          // uniform
-    const unsigned long long base = (unsigned long long)(src + g.pz * (long long)(z + 1));
-    mgx_i4 rs;
-    rs.x = (int)(unsigned)(base & 0xffffffffull);
-    rs.y = (int)(unsigned)((base >> 32) & 0xffffull);
-    rs.z = (int)plane_bytes;
-    rs.w = 0x00020000;
-#pragma unroll
-    for (int i = 0; i < NLOAD; ++i) {
-      unsigned t_;                               // never read: nobody waits for these loads
-      asm volatile("buffer_load_dword %0, %1, %2, 0 offen" : "=v"(t_) : "v"(off[i]), "s"(rs) : "memory");
-    }
-  };
-#pragma unroll
-  for (int a = 0; a < MGX_TB_PREFETCH_AHEAD; ++a) touch(k0 + 2 + a);
-  __syncthreads();                               // the barrier of the working waves before their first step
-#pragma clang loop unroll(disable)
-  for (int k = k0; k <= kend; ++k) {
-    if (k + 2 + MGX_TB_PREFETCH_AHEAD <= kend + 1) touch(k + 2 + MGX_TB_PREFETCH_AHEAD);
-    MGX_TB_SYNC();
-  }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  u64 slo = 0, shi = 0;
-  unsigned ovf = 0;
-  if (reduce & 2) {
-    __syncthreads();
-    if (bl->big != 0u)
-      mgx_block_exact_sum<T>(dst, g, tx0, min(tx0 + 127, g.n1), ty0, min(ty0 + TY - 1, g.n2), zc0, zc1, slo, shi, ovf);
-  }
-  out.lo = slo;
-  out.hi = shi;
-  out.ovf = ovf;
-}
-
 template <typename T, int NS, int TY, int BOXES, int NW, int DF>
 __device__ __forceinline__ void mgx_tb_tile(const T *__restrict__ src, T *__restrict__ dst, const MgxGeom &g,
                                             const MgxSweepParams<T> &p, const MgxBox *__restrict__ bx, const int nb,
@@ -814,10 +560,6 @@ __device__ __forceinline__ void mgx_tb_tile(const T *__restrict__ src, T *__rest
   const int tx0 = 1 + tx * 128, ty0 = 1 + ty * TY;
   const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const bool halo = wave == NW;
-  if (MGX_TB_PREFETCH && wave == NW + 1) {
-    mgx_tb_prefetch_wave<T, NS, TY, NW>(src, dst, g, tx0, ty0, zc0, zc1, reduce, res, bl, n_commit, out);
-    return;
-  }
   constexpr int RW = (TY + 4 * NS) / NW;
   // Strips of rows and waves.  The NE strips at either end of the staged region hold ring rows, which the later
   // half-sweeps do not need: less work (see ROW0).  The waves of a block go to the four SIMDs in turn, so the light
