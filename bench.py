@@ -280,6 +280,7 @@ def main():
     ap.add_argument("--no-fortran-host", action="store_true", help="skip the v-cycle solve through the Fortran host")
     ap.add_argument("--vcycle-tol", default="1.e-8")
     ap.add_argument("--sor", default="1.7")
+    ap.add_argument("--no-fp32", action="store_true", help="skip the fp32 sweeps of the same level")
     ap.add_argument("--kernel", type=int, default=0, help="0 auto, 1 two-pass, 2 fused (one sweep per pass), 3 fused with pair passes everywhere")
     ap.add_argument("--own-stream", action="store_true", help="let the library create its stream (events then see nothing)")
     ap.add_argument("--backend", default="nccl", help="torch.distributed backend for --gpus > 1 (nccl = RCCL)")
@@ -454,6 +455,32 @@ def main():
                                         "achieved": BYTES_PER_LUP * local_cells / (pk * 1e-3) / 1e9,
                                         "frac": BYTES_PER_LUP * local_cells / (pk * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                         "glups": 2 * local_cells / (pk * 1e-3) / 1e9}
+
+    if world == 1 and not args.no_fp32:
+        # the same level in real(4), the precision the reference ships (t_mg.f90:8): single sweeps with both reductions
+        # and passes of two sweeps with the error reduction; 8 B of algorithmic traffic per update, resp. per cell and pass
+        progress("the same sweeps in fp32")
+        try:
+            top32 = mgio.iomg_read(mgio.MgIO(text=config3_input(dims, tol=args.vcycle_tol, sor=args.sor)), dtype=np.float32)
+            s32 = cycle.Solver(top32, ctx=ctx)
+            s32.bring_back(top32)
+            s32.setup(top32, True)
+            l32 = top32.dev
+            for _ in range(3):
+                l32.sweep(1, RED)
+            k1, _ = timed(lambda: l32.sweep(1, RED), max(10, args.steps // 2))
+            for _ in range(2):
+                l32.sweep(2, lib.RED_ERR)
+            k2, _ = timed(lambda: l32.sweep(2, lib.RED_ERR), max(5, args.steps // 4))
+            b32 = 8.0
+            out["fp32"] = {"sweep": {"kernel_ms": k1, "glups": local_cells / (k1 * 1e-3) / 1e9, "bytes_per_lup": b32,
+                                     "frac": b32 * local_cells / (k1 * 1e-3) / 1e9 / HBM_PEAK_GBS},
+                           "pair_pass": {"kernel_ms": k2, "glups": 2 * local_cells / (k2 * 1e-3) / 1e9,
+                                         "bytes_per_cell_per_pass": b32,
+                                         "frac": b32 * local_cells / (k2 * 1e-3) / 1e9 / HBM_PEAK_GBS}}
+            s32.close()
+        except Exception as e:            # the fp64 measurement stands
+            out["fp32"] = {"error": str(e)}
 
     if world == 1:
         # the same sweep in the reference's own order (MGX_KERNEL_LEX: results of the reference on one thread, bit for

@@ -25,7 +25,7 @@ for f in glob.glob("$OUT/pmc_*/**/*counter_collection.csv", recursive=True):
     for row in csv.DictReader(open(f)):
         kn = row["Kernel_Name"]
         for key in ("k_fused_sweep", "k_tb_sweep"):
-            if key in kn:
+            if key + "<double" in kn:        # (the bench also sweeps the level in fp32: not part of these averages)
                 t = tot[key][row["Counter_Name"]]
                 t[0] += float(row["Counter_Value"]); t[1] += 1
 out["pmc_per_launch"] = {k: {c: v[0] / v[1] for c, v in d.items()} for k, d in tot.items()}
