@@ -490,7 +490,7 @@ def main():
             step()
             lk, _ = timed(step, 5)
             out["reference_order"] = {"kernel_ms": lk, "glups": local_cells / (lk * 1e-3) / 1e9,
-                                      "note": "gs in the reference's sweep order by tile hyperplanes, both reductions"}
+                                      "note": "gs in the reference's sweep order (all tiles in one launch, each waiting for the tiles before it), both reductions"}
         finally:
             ctx.set_kernel(args.kernel)
 

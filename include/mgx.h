@@ -58,9 +58,9 @@ enum { MGX_PART_EDGE = 1, MGX_PART_INNER = 2, MGX_PART_EDGE2 = 3, MGX_PART_INNER
  * sweeps per pass on the levels where that pays; TWO_PASS = one colour per launch, in place; FUSED = black and red
  * in one pass, one sweep per pass everywhere; PAIR = as FUSED, two sweeps per pass wherever that kernel applies.
  * LEX is NOT one of them: it sweeps in the reference's own order (gs, m_gs_CDS.F90:317-345: in place, z outermost, x
- * innermost; on the device by hyperplanes of tiles, one launch each), so its results are those of the reference run
- * on one thread, bit for bit, at any over-relaxation; about ten times slower than the red-black kernels; undivided levels;
- * mgx_level_sweep only (mgx_level_solve and mgx_level_sweep_part return MGX_ESTATE: loop on the host). */
+ * innermost; on the device all tiles in one launch, each waiting for the tiles before it in x, y and z), so its
+ * results are those of the reference run on one thread, bit for bit, at any over-relaxation; five to eight times
+ * slower than the red-black kernels; undivided levels; mgx_level_sweep only (mgx_level_solve and mgx_level_sweep_part return MGX_ESTATE: loop on the host). */
 enum { MGX_KERNEL_AUTO = 0, MGX_KERNEL_TWO_PASS = 1, MGX_KERNEL_FUSED = 2, MGX_KERNEL_PAIR = 3, MGX_KERNEL_LEX = 4 };
 
 const char *mgx_last_error(void);
