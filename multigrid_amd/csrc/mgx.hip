@@ -200,6 +200,7 @@ extern "C" int mgx_ctx_create(int device, void *stream, mgx_ctx **out) {
   if (const char *e = getenv("MGX_FUSED_TAIL")) mgx_fused_tail = atoi(e);
   if (const char *e = getenv("MGX_FUSED_ORDER")) mgx_fused_order = atoi(e);
   if (const char *e = getenv("MGX_FUSED_BOXCUT")) mgx_fused_boxcut = atoi(e);
+  if (const char *e = getenv("MGX_FUSED_XCD")) mgx_fused_xcd = atoi(e);
   if (const char *e = getenv("MGX_LEX_TILED")) mgx_lex_tiled = atoi(e);
   if (const char *e = getenv("MGX_SOLVE_LOOP")) mgx_solve_loop = atoi(e);  // 0: a launch per sweep in mgx_level_solve
   if (const char *e = getenv("MGX_PAIR_PASS")) mgx_pair_pass = atoi(e);   // 0 off, 1 on every level the kernel takes

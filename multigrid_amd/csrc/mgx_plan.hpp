@@ -38,6 +38,7 @@ static int mgx_fused_zc = 0;     // z chunk override (0 = automatic)
 static int mgx_fused_tail = -1;  // percent of the box-free chunks cut into halves, and half as many again into quarters (-1 = automatic)
 static int mgx_fused_order = 0;  // dispatch order of the groups of pieces, for benchmarking (see mgx_fused_make_plan)
 static int mgx_fused_boxcut = 1; // parts the chunks that boxes reach are cut into
+static int mgx_fused_xcd = 8;    // XCDs the dispatch order assumes (block b runs on XCD b mod 8), for benchmarking
 
 // (re)build the plan: which tiles can any box reach?  A tile asks about cells of its footprint grown by
 // one and about their neighbours, i.e. positions grown by two, on planes zc0-2 .. zc1+2.
@@ -161,11 +162,12 @@ static int mgx_fused_make_plan(MgxFusedPlan &pl, const MgxGeom &g, const std::ve
         if (sel == 0 || (sel == 1) == edge) v.push_back(q);
       }
       n_real += (int)v.size();
-      while (v.size() % 8) v.push_back({-1, 0, 0});
-      const size_t per = v.size() / 8;
+      const size_t NX = (size_t)(mgx_fused_xcd >= 1 && mgx_fused_xcd <= 64 ? mgx_fused_xcd : 8);
+      while (v.size() % 8 || v.size() % NX) v.push_back({-1, 0, 0});
+      const size_t per = v.size() / NX;
       const int cls = gi == 0 ? 2 : gi == 1 ? 1 : 0;         // travels in the top bits of the tile column
       for (size_t i = 0; i < v.size(); ++i) {                // block i of the group runs on XCD i mod 8: give every
-        const Piece &q = v[(i & 7) * per + (i >> 3)];        // XCD a contiguous run of the group (neighbouring tiles)
+        const Piece &q = v[(i % NX) * per + (i / NX)];       // XCD a contiguous run of the group (neighbouring tiles)
         all.push_back(q.col < 0 ? -1 : (q.col | (cls << MGX_TILE_CLASS_SHIFT))); all.push_back(q.z0); all.push_back(q.z1);
       }
       count[gi == 0 ? 0 : gi == 1 ? 1 : 2] += (int)v.size();
