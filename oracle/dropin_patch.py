@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""TEST INFRASTRUCTURE — proves the drop-in recipe of INTEGRATION.md on the reference itself.
+"""TEST INFRASTRUCTURE — applies the drop-in recipe (one library call per level operator of the reference) to the reference itself.
 
 Reads the reference's sources where they lie (REF/src), and writes into a scratch directory copies in which the
 bodies of the level operators are replaced by calls into libmgx.so; everything else — type(mg_grid)'s fields, the
