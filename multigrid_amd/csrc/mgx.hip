@@ -944,7 +944,9 @@ static int do_solve(mgx_level *lv, double tol_level, double nr, double old_sum, 
   const MgxGeom &g = lv->g;
   hipStream_t st = c->stream;
   constexpr size_t hist_bytes = sizeof(MgxSolveState) + sizeof(double) * 3 * MGX_SOLVE_LOOP_BATCH;
-  constexpr size_t state_bytes = hist_bytes + sizeof(u64) * 2 * MGX_SMALL_MAXBLOCKS * MGX_SMALL_SLOT_WORDS;   // + the slots of k_small_solve
+  constexpr size_t slot_bytes = sizeof(u64) * 2 * MGX_SMALL_MAXBLOCKS * MGX_SMALL_SLOT_WORDS;           // the slots of k_small_solve
+  constexpr size_t flag_bytes = sizeof(unsigned) * MGX_SMALL_MAXBLOCKS * MGX_SMALL_FLAG_STRIDE;         // ... and its flags
+  constexpr size_t state_bytes = hist_bytes + slot_bytes + flag_bytes;
   static_assert(MGX_SOLVE_LOOP_BATCH >= MGX_SOLVE_BATCH, "history buffer");
   if (!lv->d_solve) HIP_TRY(hipMalloc((void **)&lv->d_solve, state_bytes));
   if (!c->h_solve) HIP_TRY(hipHostMalloc((void **)&c->h_solve, state_bytes, hipHostMallocDefault));
@@ -976,6 +978,7 @@ static int do_solve(mgx_level *lv, double tol_level, double nr, double old_sum, 
         continue;
       }
       u64 *slots = reinterpret_cast<u64 *>(reinterpret_cast<char *>(lv->d_solve) + hist_bytes);
+      HIP_TRY(hipMemsetAsync(reinterpret_cast<char *>(slots) + slot_bytes, 0, flag_bytes, st));   // meetings count from 1 in every launch
       hipLaunchKernelGGL((k_small_solve<T>), dim3((unsigned)blocks), dim3(256), 0, st, (T *)lv->buf[cur0], (T *)lv->buf[1 - cur0], g, p,
                          lv->d_boxes, lv->nbox, lv->d_res, lv->d_solve, d_hist, slots, MGX_SOLVE_LOOP_BATCH, tol_level, nr, batch);
     }

@@ -8,9 +8,11 @@
 // arithmetic on the same operands, hence the same bits) and then the red cell: 25 loads, 7 cell updates and 2 stores per
 // pair.  Nothing a sweep writes is read in the same sweep, so ONE meeting of all blocks per sweep is enough.  The
 // blocks' reductions travel with that meeting: every block stores its partial result into a slot of its own (two sets
-// of slots, by the parity of the sweep), waits for its stores, counts itself and polls the count; after the meeting
-// every block reads all slots, folds them and evaluates the test of the loop (tol = |old_sum - new_sum| * nr against
-// the level's tolerance, in the level's precision), so all blocks reach the same verdict without another hand-off.
+// of slots, by the parity of the sweep), waits for its stores and counts itself.  The block whose count is the last
+// one finds every slot in memory: it folds them, evaluates the test of the loop (tol = |old_sum - new_sum| * nr against
+// the level's tolerance, in the level's precision), keeps the history and raises a flag for every block — each in a
+// line of its own — that carries the number of the meeting and the verdict; the other blocks poll their own flag only
+// (256 blocks polling one word, or all reading all slots, queue up at the memory side for microseconds).
 // Cell arithmetic, reductions, history and sweep counts are those of the launch-per-sweep forms, bit for bit.
 //
 // Hand-off between blocks inside the launch (other compute units, other L2s): the field and the slots are read and
@@ -41,32 +43,7 @@ __device__ __forceinline__ void mgx_dev_store(float *p, const float v) {
   __hip_atomic_store((unsigned *)p, __float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
-// Meeting number m (1, 2, ... within the launch) of all blocks: every block counts itself and waits until all have.
-// Returns 0, or 3 when some block gave up waiting.  Every thread of every block calls it.
-__device__ __forceinline__ int mgx_meet(MgxSolveState *__restrict__ stt, u64 *__restrict__ res, const unsigned m, int *verdict) {
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");          // this thread's stores have left for memory and arrived
-  __syncthreads();
-  if (threadIdx.x == 0) {
-    const unsigned want = gridDim.x * m;
-    __hip_atomic_fetch_add(&stt->arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    int v = 0, spins = 0;
-    for (;;) {
-      if (__hip_atomic_load(&stt->arrive, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= want) break;
-      // (a block that finds the error word raised does not wait on: a launch that lost one block drains at once)
-      if (++spins > MGX_SMALL_MAXSPIN ||
-          ((spins & 63) == 0 && __hip_atomic_load(res + MGX_RES_ERRWORD, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0ull)) {
-        __hip_atomic_fetch_or(res + MGX_RES_ERRWORD, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        __hip_atomic_store(&stt->gen, 3u << 28, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        v = 3;
-        break;
-      }
-      __builtin_amdgcn_s_sleep(1);
-    }
-    *verdict = v;
-  }
-  __syncthreads();
-  return *verdict;
-}
+#define MGX_SMALL_FLAG_STRIDE 16         /* 32-bit words between the flags of two blocks (64 bytes) */
 
 // max of word 0 and sums of words 1..5 over the 256 threads of a block; the result is valid in thread 0
 __device__ __forceinline__ void mgx_small_fold(u64 (&w)[6], u64 (*sh)[6]) {
@@ -117,7 +94,8 @@ __device__ inline unsigned mgx_small_kind(const MgxGeom &g, const MgxBox *__rest
   return 0u;
 }
 
-// `slots`: 2 * MGX_SMALL_MAXBLOCKS * MGX_SMALL_SLOT_WORDS words
+// `slots`: 2 * MGX_SMALL_MAXBLOCKS * MGX_SMALL_SLOT_WORDS words, then MGX_SMALL_MAXBLOCKS * MGX_SMALL_FLAG_STRIDE 32-bit
+// flags, zero at the launch
 template <typename T>
 __global__ __launch_bounds__(256) void k_small_solve(T *__restrict__ buf_a, T *__restrict__ buf_b, const MgxGeom g,
                                                      const MgxSweepParams<T> p, const MgxBox *__restrict__ bx, const int nb,
@@ -125,8 +103,9 @@ __global__ __launch_bounds__(256) void k_small_solve(T *__restrict__ buf_a, T *_
                                                      double *__restrict__ hist, u64 *__restrict__ slots, const int cap,
                                                      const double gtol, const double nr, const int batch) {
   constexpr int CPT = MGX_SMALL_CPT;
-  __shared__ int verdict;
+  __shared__ int verdict, last;
   __shared__ u64 sh[4][6];
+  unsigned *const flags = reinterpret_cast<unsigned *>(slots + 2 * MGX_SMALL_MAXBLOCKS * MGX_SMALL_SLOT_WORDS);
   const int nthreads = (int)gridDim.x * 256, tid = (int)blockIdx.x * 256 + (int)threadIdx.x;
   const int hx = (g.n1 + 1) / 2;                            // pairs of a row (the last may hold one cell only)
   const int npair = hx * g.n2 * g.n3;
@@ -206,7 +185,6 @@ __global__ __launch_bounds__(256) void k_small_solve(T *__restrict__ buf_a, T *_
     }
   };
 
-  T old_sum = (T)stt->old_sum;                 // (written before the launch)
   load_all(buf_a);
   for (int j = 0; j < batch; ++j) {
     T *dst = (j & 1) ? buf_a : buf_b;
@@ -257,38 +235,79 @@ __global__ __launch_bounds__(256) void k_small_solve(T *__restrict__ buf_a, T *_
 #pragma unroll
       for (int k = 0; k < 6; ++k) __hip_atomic_store(set + blockIdx.x * MGX_SMALL_SLOT_WORDS + k, w[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     }
-    if (mgx_meet(stt, res, (unsigned)(j + 1), &verdict) != 0) return;          // (3: some block gave up)
-    if (j + 1 < batch) load_all(dst);                                          // the next sweep reads what this one wrote
-
-    // ---- every block folds all slots and evaluates the test itself ----
-#pragma unroll
-    for (int k = 0; k < 6; ++k)
-      w[k] = threadIdx.x < gridDim.x ? __hip_atomic_load(set + threadIdx.x * MGX_SMALL_SLOT_WORDS + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
-    mgx_small_fold(w, sh);
+    // ---- the meeting.  Every block counts itself; the block whose count is the last one finds every slot in memory:
+    // it folds them, evaluates the test of the loop and raises a flag for every block (each in a line of its own) that
+    // carries the number of the meeting and the verdict.  The others poll their own flag only: polls of one word by
+    // every block, and 256 blocks reading all slots, would queue up at the memory side for microseconds. ----
+    const unsigned m = (unsigned)(j + 1);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // this thread's stores have left for memory and arrived
+    __syncthreads();
     if (threadIdx.x == 0) {
-      // positional sum of the four digits (they may exceed 32 bits), as mgx_solve_check
-      u64 slo = w[1], shi = w[3] + (w[4] << 32);
-      const u64 a = w[2] << 32;
-      slo += a;
-      shi += (w[2] >> 32) + (slo < a ? 1ull : 0ull);
-      const bool bad = w[5] != 0ull;
-      const double sum = bad ? __longlong_as_double(0x7ff8000000000000LL) : mgx_limbs_to_double_dev(slo, shi);
-      const T new_sum = (T)sum;
-      const T diff = old_sum - new_sum;
-      const T tol = (diff < (T)0 ? -diff : diff) * (T)nr;
-      const int stop = bad ? 2 : ((double)tol > gtol ? 0 : 1);
-      old_sum = new_sum;
-      if (blockIdx.x == 0) {                   // the history, the state the host reads, and the level's result record
-        if (j < cap) { hist[3 * j] = (double)tol; hist[3 * j + 1] = (double)new_sum; hist[3 * j + 2] = __longlong_as_double((long long)w[0]); }
-        stt->count = j + 1;
-        stt->old_sum = (double)new_sum;
-        stt->stop = stop;
-#pragma unroll
-        for (int k = 0; k < 6; ++k) res[k] = w[k];
-      }
-      verdict = stop;
+      const unsigned mine = __hip_atomic_fetch_add(&stt->arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      last = mine == gridDim.x * m - 1u ? 1 : 0;
+      verdict = 0;
     }
     __syncthreads();
+    if (last) {
+#pragma unroll
+      for (int k = 0; k < 6; ++k)
+        w[k] = threadIdx.x < gridDim.x ? __hip_atomic_load(set + threadIdx.x * MGX_SMALL_SLOT_WORDS + k, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0ull;
+      mgx_small_fold(w, sh);
+      if (threadIdx.x == 0) {
+        // positional sum of the four digits (they may exceed 32 bits), as mgx_solve_check
+        u64 slo = w[1], shi = w[3] + (w[4] << 32);
+        const u64 a = w[2] << 32;
+        slo += a;
+        shi += (w[2] >> 32) + (slo < a ? 1ull : 0ull);
+        const bool bad = w[5] != 0ull;
+        const double sum = bad ? __longlong_as_double(0x7ff8000000000000LL) : mgx_limbs_to_double_dev(slo, shi);
+        // (the sum before this sweep: written by the host before the launch or by the last block of the sweep before)
+        const T old_sum = (T)__longlong_as_double((long long)__hip_atomic_load((u64 *)&stt->old_sum, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT));
+        const T new_sum = (T)sum;
+        const T diff = old_sum - new_sum;
+        const T tol = (diff < (T)0 ? -diff : diff) * (T)nr;
+        const int stop = bad ? 2 : ((double)tol > gtol ? 0 : 1);
+        // the history, the state the host reads, and the level's result record: words that the last blocks of other
+        // sweeps (other compute units, other L2s) write too, so device-scope stores here as well: plain ones would sit
+        // in this XCD's L2 until the launch ends and could land on top of a later sweep's
+        if (j < cap) {
+          mgx_dev_store(hist + 3 * j, (double)tol);
+          mgx_dev_store(hist + 3 * j + 1, (double)new_sum);
+          mgx_dev_store(hist + 3 * j + 2, __longlong_as_double((long long)w[0]));
+        }
+        __hip_atomic_store(&stt->count, j + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store(&stt->stop, stop, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        __hip_atomic_store((u64 *)&stt->old_sum, (u64)__double_as_longlong((double)new_sum), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#pragma unroll
+        for (int k = 0; k < 6; ++k) __hip_atomic_store(res + k, w[k], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");    // (old_sum is in memory before any block can get to the next meeting)
+        verdict = stop;
+      }
+      __syncthreads();
+      if (threadIdx.x < gridDim.x)
+        __hip_atomic_store(flags + threadIdx.x * MGX_SMALL_FLAG_STRIDE, m | ((unsigned)verdict << 28), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    } else {
+      if (threadIdx.x == 0) {
+        unsigned *const mine = flags + blockIdx.x * MGX_SMALL_FLAG_STRIDE;
+        int spins = 0, v = 0;
+        for (;;) {
+          const unsigned f = __hip_atomic_load(mine, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          if ((f & 0x0fffffffu) >= m) { v = (int)(f >> 28); break; }
+          // (a block that finds the error word raised does not wait on: a launch that lost one block drains at once)
+          if (++spins > MGX_SMALL_MAXSPIN ||
+              ((spins & 63) == 0 && __hip_atomic_load(res + MGX_RES_ERRWORD, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0ull)) {
+            __hip_atomic_fetch_or(res + MGX_RES_ERRWORD, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&stt->gen, 3u << 28, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            v = 3;
+            break;
+          }
+          __builtin_amdgcn_s_sleep(1);
+        }
+        verdict = v;
+      }
+      __syncthreads();
+    }
     if (verdict != 0) return;
+    if (j + 1 < batch) load_all(dst);                        // the next sweep reads what this one wrote
   }
 }
