@@ -945,7 +945,7 @@ static int do_solve(mgx_level *lv, double tol_level, double nr, double old_sum, 
   hipStream_t st = c->stream;
   constexpr size_t hist_bytes = sizeof(MgxSolveState) + sizeof(double) * 3 * MGX_SOLVE_LOOP_BATCH;
   constexpr size_t slot_bytes = sizeof(u64) * 2 * MGX_SMALL_MAXBLOCKS * MGX_SMALL_SLOT_WORDS;           // the slots of k_small_solve
-  constexpr size_t flag_bytes = sizeof(unsigned) * MGX_SMALL_MAXBLOCKS * MGX_SMALL_FLAG_STRIDE;         // ... and its flags
+  constexpr size_t flag_bytes = sizeof(unsigned) * MGX_SMALL_FLAG_WORDS;                                // ... and its flags and counters
   constexpr size_t state_bytes = hist_bytes + slot_bytes + flag_bytes;
   static_assert(MGX_SOLVE_LOOP_BATCH >= MGX_SOLVE_BATCH, "history buffer");
   if (!lv->d_solve) HIP_TRY(hipMalloc((void **)&lv->d_solve, state_bytes));

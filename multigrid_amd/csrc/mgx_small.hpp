@@ -44,6 +44,8 @@ __device__ __forceinline__ void mgx_dev_store(float *p, const float v) {
 }
 
 #define MGX_SMALL_FLAG_STRIDE 16         /* 32-bit words between the flags of two blocks (64 bytes) */
+#define MGX_SMALL_GROUP 16               /* blocks that share an arrival counter */
+#define MGX_SMALL_FLAG_WORDS ((MGX_SMALL_MAXBLOCKS + 1 + MGX_SMALL_MAXBLOCKS / MGX_SMALL_GROUP) * MGX_SMALL_FLAG_STRIDE)
 
 // max of word 0 and sums of words 1..5 over the 256 threads of a block; the result is valid in thread 0
 __device__ __forceinline__ void mgx_small_fold(u64 (&w)[6], u64 (*sh)[6]) {
@@ -94,8 +96,8 @@ __device__ inline unsigned mgx_small_kind(const MgxGeom &g, const MgxBox *__rest
   return 0u;
 }
 
-// `slots`: 2 * MGX_SMALL_MAXBLOCKS * MGX_SMALL_SLOT_WORDS words, then MGX_SMALL_MAXBLOCKS * MGX_SMALL_FLAG_STRIDE 32-bit
-// flags, zero at the launch
+// `slots`: 2 * MGX_SMALL_MAXBLOCKS * MGX_SMALL_SLOT_WORDS words, then MGX_SMALL_FLAG_WORDS 32-bit words (a flag per
+// block, then the arrival counters), zero at the launch
 template <typename T>
 __global__ __launch_bounds__(256) void k_small_solve(T *__restrict__ buf_a, T *__restrict__ buf_b, const MgxGeom g,
                                                      const MgxSweepParams<T> p, const MgxBox *__restrict__ bx, const int nb,
@@ -243,8 +245,15 @@ __global__ __launch_bounds__(256) void k_small_solve(T *__restrict__ buf_a, T *_
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");        // this thread's stores have left for memory and arrived
     __syncthreads();
     if (threadIdx.x == 0) {
-      const unsigned mine = __hip_atomic_fetch_add(&stt->arrive, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      last = mine == gridDim.x * m - 1u ? 1 : 0;
+      // counted in two levels, groups of MGX_SMALL_GROUP blocks first (a counter per group, each in a line of its own),
+      // then the groups: atomics on one word are served one after the other
+      const unsigned grp = blockIdx.x / MGX_SMALL_GROUP, ngrp = (gridDim.x + MGX_SMALL_GROUP - 1) / MGX_SMALL_GROUP;
+      const unsigned gsize = min((unsigned)MGX_SMALL_GROUP, gridDim.x - grp * MGX_SMALL_GROUP);
+      unsigned *const cnt = flags + MGX_SMALL_MAXBLOCKS * MGX_SMALL_FLAG_STRIDE;
+      int l = 0;
+      if (__hip_atomic_fetch_add(cnt + (1 + grp) * MGX_SMALL_FLAG_STRIDE, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == gsize * m - 1u)
+        l = __hip_atomic_fetch_add(cnt, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == ngrp * m - 1u ? 1 : 0;
+      last = l;
       verdict = 0;
     }
     __syncthreads();
