@@ -61,6 +61,13 @@ __global__ __launch_bounds__(MGX_LEXC_NT) void k_lex_chain(T *__restrict__ V, co
   T err = (T)0;
   if (BOXED && lane < nb) sbx[lane] = bx[lane];
   if (lane == 0) lost_ = 0;
+#ifdef MGX_LEXC_STAMPS          /* experiment builds: where the time of a tile goes (printed by a few tiles) */
+  unsigned long long ts[6];
+#define MGX_LSTAMP(i) { unsigned long long t_; asm volatile("s_memrealtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t_) :: "memory"); ts[i] = t_; }
+#else
+#define MGX_LSTAMP(i)
+#endif
+  MGX_LSTAMP(0)
 
   // ---- what was written before this launch: own cells and the faces towards x+1, y+1, z+1 (plain loads) ----
   {
@@ -84,56 +91,9 @@ __global__ __launch_bounds__(MGX_LEXC_NT) void k_lex_chain(T *__restrict__ V, co
     }
   }
 
-  // ---- wait for the tiles before this one in x, y, z ----
-  if (lane < 64) {                                         // (the first wave polls; the others wait at the barrier)
-    int want = -1;
-    if (lane == 0 && I > 0) want = self - 1;
-    if (lane == 1 && J > 0) want = self - ntx;
-    if (lane == 2 && K > 0) want = self - ntx * nty;
-    int spins = 0;
-    for (;;) {
-      int v = epoch;
-      if (want >= 0) v = __hip_atomic_load(done + want, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      if (!__any(v - epoch < 0)) break;
-      // (a tile that finds the error word raised does not wait at all: a launch that lost one tile drains at once)
-      if (++spins > MGX_LEXC_MAXSPIN ||
-          ((spins & 255) == 0 && __hip_atomic_load(res + MGX_RES_ERRWORD, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0ull)) {
-        if (lane == 0) lost_ = 1;
-        break;
-      }
-      __builtin_amdgcn_s_sleep(2);
-    }
-  }
-  __syncthreads();
-
-  // ---- the three faces the predecessors wrote in this launch: sc1 loads of 4 bytes ----
-  {
-    // face elements: x-1 face (ny nz), y-1 face (nx nz), z-1 face (nx ny); ghosts of the level come the same way
-    const int n_a = ny * nz, n_b = nx * nz, n_c = nx * ny, n_all = n_a + n_b + n_c;
-    const unsigned long long base = (unsigned long long)(V + g.idx(x0 - 1, y0 - 1, z0 - 1));
-    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
-        (void *)base, 0, (int)min((long long)0x7fffffff, (long long)sizeof(T) * ((long long)(TZ + 2) * g.pz)), 0x00020000);
-    constexpr int PER = (TY * TZ + TX * TZ + TX * TY + NT - 1) / NT;   // bound of n_all / NT
-#pragma unroll
-    for (int u = 0; u < PER; ++u) {
-      const int e = u * NT + lane;
-      int xx = 0, yy = 0, zz = 0;
-      const bool ok = e < n_all;
-      if (e < n_a) { xx = 0; yy = e % ny + 1; zz = e / ny + 1; }
-      else if (e < n_a + n_b) { const int f = e - n_a; xx = f % nx + 1; yy = 0; zz = f / nx + 1; }
-      else { const int f = e - n_a - n_b; xx = f % nx + 1; yy = f / nx + 1; zz = 0; }
-      const long long el = xx + (long long)g.px * yy + g.pz * zz;
-      const int off = ok ? (int)(el * (long long)sizeof(T)) : (int)0x7ffffff0;     // beyond the records: not loaded
-      unsigned w[2] = {0u, 0u};
-#pragma unroll
-      for (int h = 0; h < WPE; ++h) w[h] = __builtin_amdgcn_raw_buffer_load_b32(rs, off + 4 * h, 0, 16 /* sc1 */);
-      T val;
-      if constexpr (sizeof(T) == 8) val = __hiloint2double((int)w[1], (int)w[0]); else val = __uint_as_float(w[0]);
-      if (ok) t[zz * PY + yy * PX + xx] = val;
-    }
-  }
-  __syncthreads();
-
+  // ---- box codes of the tile's cells and the weight tables: nothing here depends on the tiles before, so it is done
+  // ahead of the wait ----
+  __syncthreads();                                         // (the box table is in LDS)
   const int cls = BOXED ? mgx_classify(sbx, nb, x0, x0 + nx - 1, y0, y0 + ny - 1, z0 + g.z0, z0 + nz - 1 + g.z0) : 0;
   const int j = lane % TY, k = lane / TY;
   const bool coded = BOXED && cls != 0;
@@ -180,6 +140,59 @@ __global__ __launch_bounds__(MGX_LEXC_NT) void k_lex_chain(T *__restrict__ V, co
     }
   }
 
+  MGX_LSTAMP(1)
+  // ---- wait for the tiles before this one in x, y, z ----
+  if (lane < 64) {                                         // (the first wave polls; the others wait at the barrier)
+    int want = -1;
+    if (lane == 0 && I > 0) want = self - 1;
+    if (lane == 1 && J > 0) want = self - ntx;
+    if (lane == 2 && K > 0) want = self - ntx * nty;
+    int spins = 0;
+    for (;;) {
+      int v = epoch;
+      if (want >= 0) v = __hip_atomic_load(done + want, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (!__any(v - epoch < 0)) break;
+      // (a tile that finds the error word raised does not wait at all: a launch that lost one tile drains at once)
+      if (++spins > MGX_LEXC_MAXSPIN ||
+          ((spins & 255) == 0 && __hip_atomic_load(res + MGX_RES_ERRWORD, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0ull)) {
+        if (lane == 0) lost_ = 1;
+        break;
+      }
+      __builtin_amdgcn_s_sleep(2);
+    }
+  }
+  __syncthreads();
+
+  MGX_LSTAMP(2)
+  // ---- the three faces the predecessors wrote in this launch: sc1 loads of 4 bytes ----
+  {
+    // face elements: x-1 face (ny nz), y-1 face (nx nz), z-1 face (nx ny); ghosts of the level come the same way
+    const int n_a = ny * nz, n_b = nx * nz, n_c = nx * ny, n_all = n_a + n_b + n_c;
+    const unsigned long long base = (unsigned long long)(V + g.idx(x0 - 1, y0 - 1, z0 - 1));
+    const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(
+        (void *)base, 0, (int)min((long long)0x7fffffff, (long long)sizeof(T) * ((long long)(TZ + 2) * g.pz)), 0x00020000);
+    constexpr int PER = (TY * TZ + TX * TZ + TX * TY + NT - 1) / NT;   // bound of n_all / NT
+#pragma unroll
+    for (int u = 0; u < PER; ++u) {
+      const int e = u * NT + lane;
+      int xx = 0, yy = 0, zz = 0;
+      const bool ok = e < n_all;
+      if (e < n_a) { xx = 0; yy = e % ny + 1; zz = e / ny + 1; }
+      else if (e < n_a + n_b) { const int f = e - n_a; xx = f % nx + 1; yy = 0; zz = f / nx + 1; }
+      else { const int f = e - n_a - n_b; xx = f % nx + 1; yy = f / nx + 1; zz = 0; }
+      const long long el = xx + (long long)g.px * yy + g.pz * zz;
+      const int off = ok ? (int)(el * (long long)sizeof(T)) : (int)0x7ffffff0;     // beyond the records: not loaded
+      unsigned w[2] = {0u, 0u};
+#pragma unroll
+      for (int h = 0; h < WPE; ++h) w[h] = __builtin_amdgcn_raw_buffer_load_b32(rs, off + 4 * h, 0, 16 /* sc1 */);
+      T val;
+      if constexpr (sizeof(T) == 8) val = __hiloint2double((int)w[1], (int)w[0]); else val = __uint_as_float(w[0]);
+      if (ok) t[zz * PY + yy * PX + xx] = val;
+    }
+  }
+  __syncthreads();
+
+  MGX_LSTAMP(3)
   // ---- the tile by its own hyperplanes i + j + k = m: lane = (j, k), every operand in LDS ----
   const bool mine = j < ny && k < nz;
   T *c0 = t + (k + 1) * PY + (j + 1) * PX + 1;
@@ -216,6 +229,7 @@ __global__ __launch_bounds__(MGX_LEXC_NT) void k_lex_chain(T *__restrict__ V, co
     __syncthreads();
   }
 
+  MGX_LSTAMP(4)
   // ---- the tile back: whole lines, 16 bytes a lane, sc1; then the counter ----
   {
     const unsigned long long base = (unsigned long long)(V + g.idx(x0, y0, z0));
@@ -257,6 +271,12 @@ __global__ __launch_bounds__(MGX_LEXC_NT) void k_lex_chain(T *__restrict__ V, co
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
+  MGX_LSTAMP(5)
+#ifdef MGX_LEXC_STAMPS
+  if (lane == 0 && ((I == ntx / 2 && J == nty / 2) || (I == 2 && J == 2)) && (K & 7) == 3 && epoch == 3)
+    printf("tile %d %d %d (x 10 ns): stage own %llu  wait %llu  faces %llu  codes %llu  steps %llu  store+drain %llu\n", I, J, K,
+           ts[1] - ts[0], ts[2] - ts[1], ts[3] - ts[2], 0ull, ts[4] - ts[3], ts[5] - ts[4]);
+#endif
   if (lane == 0) {
     __hip_atomic_fetch_add(done + self, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (lost_) __hip_atomic_fetch_or(res + MGX_RES_ERRWORD, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
