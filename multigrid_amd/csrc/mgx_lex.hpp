@@ -196,6 +196,19 @@ __global__ __launch_bounds__(MGX_LEXC_NT) void k_lex_chain(T *__restrict__ V, co
   // ---- the tile by its own hyperplanes i + j + k = m: lane = (j, k), every operand in LDS ----
   const bool mine = j < ny && k < nz;
   T *c0 = t + (k + 1) * PY + (j + 1) * PX + 1;
+  // the codes of the thread's row into registers (a step then reads its weights and its values in one trip to LDS
+  // instead of the code first); rows of 16 cells only: picking a byte out of eight registers costs what it saves
+  constexpr bool CODES_IN_REGS = TX / 4 <= 4;
+  unsigned cw[TX / 4];
+#pragma unroll
+  for (int q = 0; q < TX / 4; ++q) cw[q] = 0u;
+  if constexpr (BOXED) {
+    if (CODES_IN_REGS && coded && mine) {
+      const unsigned *row = reinterpret_cast<const unsigned *>(&bl_[0].code[(k * TY + j) * TX]);
+#pragma unroll
+      for (int q = 0; q < TX / 4; ++q) cw[q] = row[q];
+    }
+  }
   for (int m = 0; m < nx + ny + nz - 2; ++m) {
     const int i = m - j - k;
     if (mine && i >= 0 && i < nx) {
@@ -206,7 +219,15 @@ __global__ __launch_bounds__(MGX_LEXC_NT) void k_lex_chain(T *__restrict__ V, co
       if constexpr (BOXED) {
         if (coded) {
           const MgxLexcBoxLds<T> &bl = bl_[0];
-          const unsigned code = bl.code[(k * TY + j) * TX + i];
+          unsigned code;
+          if constexpr (CODES_IN_REGS) {
+            unsigned word = cw[0];
+#pragma unroll
+            for (int q = 1; q < TX / 4; ++q) word = (i >> 2) == q ? cw[q] : word;
+            code = (word >> ((i & 3) * 8)) & 255u;
+          } else {
+            code = bl.code[(k * TY + j) * TX + i];
+          }
           const T *w = &bl.wtab[0][0][0] + (code & 127u) * 6u;
           T avg = c[-1] * w[0] + c[1] * w[1];
           avg = avg + c[-PX] * w[2];
