@@ -30,9 +30,6 @@ template <typename T>
 struct MgxLexcBoxLds {
   unsigned xs[128 / sizeof(T) + 2], ys[MGX_LEXC_CY + 2], zs[MGX_LEXC_CZ + 2];
   T wtab[2][64][6];
-  // per cell: bit 7 = constant cell, bits 0..6 = row of wtab (table << 6 | mask of the neighbours inside that table's
-  // box); row 64 (second table, no neighbour inside: cannot occur) stands for "general weights"
-  unsigned char code[MGX_LEXC_CZ * MGX_LEXC_CY * (128 / sizeof(T))];
 };
 
 typedef unsigned mgx_lx_u4 __attribute__((ext_vector_type(4)));
@@ -47,10 +44,24 @@ __global__ __launch_bounds__(MGX_LEXC_NT) void k_lex_chain(T *__restrict__ V, co
   constexpr int TX = 128 / (int)sizeof(T), TY = MGX_LEXC_CY, TZ = MGX_LEXC_CZ, NT = MGX_LEXC_NT;
   static_assert(NT % 64 == 0 && NT <= 1024, "one thread per (row, plane) of a tile, whole waves");
   __shared__ int lost_;
-  constexpr int PX = TX + 3, PY = (TY + 2) * PX;          // pitches of the staged tile (row, plane), in elements
+#ifdef MGX_LEXC_PAD             /* experiment builds: LDS nobody uses, to keep a compute unit to one tile at a time */
+  __shared__ char pad_[MGX_LEXC_PAD];
+  if (threadIdx.x == 0 && g.n1 < 0) pad_[0] = 1;
+#endif
+#ifndef MGX_LEXC_PXPAD
+#define MGX_LEXC_PXPAD 2
+#endif
+  constexpr int PX = TX + MGX_LEXC_PXPAD, PY = (TY + 2) * PX;   // pitches of the staged tile (row, plane), in elements
   constexpr int WPE = (int)sizeof(T) / 4;                  // 32-bit words per element
   __shared__ T t[(TZ + 2) * PY];
+#ifdef MGX_LEXC_SBX_LDS          /* experiment builds: the box table in LDS (two tiles to a compute unit) */
   __shared__ MgxBox sbx[BOXED ? 32 : 1];
+  if (BOXED && (int)threadIdx.x < nb) sbx[threadIdx.x] = bx[threadIdx.x];
+  __syncthreads();
+#else
+  const MgxBox *__restrict__ const sbx = bx;               // (the box table is read where it lies: LDS is kept for tiles,
+                                                           // three of them to a compute unit)
+#endif
   __shared__ typename std::conditional<BOXED, MgxLexcBoxLds<T>, char>::type bl_[1];
   const int lane = threadIdx.x;
   const int ent = order[blockIdx.x];
@@ -59,7 +70,6 @@ __global__ __launch_bounds__(MGX_LEXC_NT) void k_lex_chain(T *__restrict__ V, co
   const int nx = min(TX, g.n1 - x0 + 1), ny = min(TY, g.n2 - y0 + 1), nz = min(TZ, g.n3 - z0 + 1);
   const int self = I + ntx * (J + nty * K);
   T err = (T)0;
-  if (BOXED && lane < nb) sbx[lane] = bx[lane];
   if (lane == 0) lost_ = 0;
 #ifdef MGX_LEXC_STAMPS          /* experiment builds: where the time of a tile goes (printed by a few tiles) */
   unsigned long long ts[6];
@@ -93,10 +103,15 @@ __global__ __launch_bounds__(MGX_LEXC_NT) void k_lex_chain(T *__restrict__ V, co
 
   // ---- box codes of the tile's cells and the weight tables: nothing here depends on the tiles before, so it is done
   // ahead of the wait ----
-  __syncthreads();                                         // (the box table is in LDS)
   const int cls = BOXED ? mgx_classify(sbx, nb, x0, x0 + nx - 1, y0, y0 + ny - 1, z0 + g.z0, z0 + nz - 1 + g.z0) : 0;
   const int j = lane % TY, k = lane / TY;
   const bool coded = BOXED && cls != 0;
+  // per cell of the thread's row one byte of code, kept in registers: bit 7 = constant cell, bits 0..6 = row of wtab
+  // (table << 6 | mask of the neighbours inside that table's box); row 64 (second table, no neighbour inside: cannot
+  // occur) stands for "general weights"
+  unsigned cw[TX / 4];
+#pragma unroll
+  for (int q = 0; q < TX / 4; ++q) cw[q] = 0u;
   if constexpr (BOXED) {
     if (coded) {
       MgxLexcBoxLds<T> &bl = bl_[0];
@@ -131,12 +146,19 @@ __global__ __launch_bounds__(MGX_LEXC_NT) void k_lex_chain(T *__restrict__ V, co
       if (j < ny && k < nz) {
         const uint4 ys4 = make_uint4(bl.ys[j], bl.ys[j + 1], bl.ys[j + 2], 0u);
         const unsigned zl = bl.zs[k], zc = bl.zs[k + 1], zh = bl.zs[k + 2];
-        for (int i = 0; i < nx; ++i) {
-          const unsigned c9 = mgx_cell_code(bl.xs[i + 1], bl.xs[i], bl.xs[i + 2], ys4, zl, zc, zh, cmask, rmask, tb0, tb1);
-          bl.code[(k * TY + j) * TX + i] = (unsigned char)((c9 & MGX_CODE_GENERAL) ? ((c9 & MGX_CODE_CONST) | 64u) : (c9 & 255u));
+#pragma unroll
+        for (int q = 0; q < TX / 4; ++q) {                  // (one register at a time, its four cells in a loop: short code)
+          unsigned w4 = 0u;
+#pragma unroll 1
+          for (int b4 = 0; b4 < 4; ++b4) {
+            const int i = 4 * q + b4;
+            const unsigned c9 = i < nx ? mgx_cell_code(bl.xs[i + 1], bl.xs[i], bl.xs[i + 2], ys4, zl, zc, zh, cmask, rmask, tb0, tb1) : 0u;
+            const unsigned c8 = (c9 & MGX_CODE_GENERAL) ? ((c9 & MGX_CODE_CONST) | 64u) : (c9 & 255u);
+            w4 |= c8 << (b4 * 8);
+          }
+          cw[q] = w4;
         }
       }
-      __syncthreads();
     }
   }
 
@@ -196,19 +218,6 @@ __global__ __launch_bounds__(MGX_LEXC_NT) void k_lex_chain(T *__restrict__ V, co
   // ---- the tile by its own hyperplanes i + j + k = m: lane = (j, k), every operand in LDS ----
   const bool mine = j < ny && k < nz;
   T *c0 = t + (k + 1) * PY + (j + 1) * PX + 1;
-  // the codes of the thread's row into registers (a step then reads its weights and its values in one trip to LDS
-  // instead of the code first); rows of 16 cells only: picking a byte out of eight registers costs what it saves
-  constexpr bool CODES_IN_REGS = TX / 4 <= 4;
-  unsigned cw[TX / 4];
-#pragma unroll
-  for (int q = 0; q < TX / 4; ++q) cw[q] = 0u;
-  if constexpr (BOXED) {
-    if (CODES_IN_REGS && coded && mine) {
-      const unsigned *row = reinterpret_cast<const unsigned *>(&bl_[0].code[(k * TY + j) * TX]);
-#pragma unroll
-      for (int q = 0; q < TX / 4; ++q) cw[q] = row[q];
-    }
-  }
   for (int m = 0; m < nx + ny + nz - 2; ++m) {
     const int i = m - j - k;
     if (mine && i >= 0 && i < nx) {
@@ -219,15 +228,10 @@ __global__ __launch_bounds__(MGX_LEXC_NT) void k_lex_chain(T *__restrict__ V, co
       if constexpr (BOXED) {
         if (coded) {
           const MgxLexcBoxLds<T> &bl = bl_[0];
-          unsigned code;
-          if constexpr (CODES_IN_REGS) {
-            unsigned word = cw[0];
+          unsigned word = cw[0];           // (a step reads its weights and its values in one trip to LDS)
 #pragma unroll
-            for (int q = 1; q < TX / 4; ++q) word = (i >> 2) == q ? cw[q] : word;
-            code = (word >> ((i & 3) * 8)) & 255u;
-          } else {
-            code = bl.code[(k * TY + j) * TX + i];
-          }
+          for (int q = 1; q < TX / 4; ++q) word = (i >> 2) == q ? cw[q] : word;
+          const unsigned code = (word >> ((i & 3) * 8)) & 255u;
           const T *w = &bl.wtab[0][0][0] + (code & 127u) * 6u;
           T avg = c[-1] * w[0] + c[1] * w[1];
           avg = avg + c[-PX] * w[2];
