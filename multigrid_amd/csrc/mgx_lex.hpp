@@ -24,6 +24,9 @@
 #define MGX_LEXC_CZ 16
 #endif
 #define MGX_LEXC_NT (MGX_LEXC_CY * MGX_LEXC_CZ)
+#ifndef MGX_LEXC_BATCH
+#define MGX_LEXC_BATCH 20                 /* loads a thread keeps in flight while it stages the tile's own cells */
+#endif
 #define MGX_LEXC_MAXSPIN (1 << 19)       /* polls before a tile gives up (each takes a microsecond or more) */
 
 template <typename T>
@@ -82,7 +85,7 @@ __global__ __launch_bounds__(MGX_LEXC_NT) void k_lex_chain(T *__restrict__ V, co
   // ---- what was written before this launch: own cells and the faces towards x+1, y+1, z+1 (plain loads) ----
   {
     const T *const org = V + g.idx(x0 - 1, y0 - 1, z0 - 1);
-    constexpr int RW = TX + 1, BATCH = 8, NB = ((TY + 1) * (TZ + 1) * RW + NT * BATCH - 1) / (NT * BATCH);
+    constexpr int RW = TX + 1, BATCH = MGX_LEXC_BATCH, NB = ((TY + 1) * (TZ + 1) * RW + NT * BATCH - 1) / (NT * BATCH);
 #pragma unroll 1
     for (int b = 0; b < NB; ++b) {
       T tmp[BATCH];
