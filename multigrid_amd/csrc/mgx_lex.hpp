@@ -221,11 +221,17 @@ __global__ __launch_bounds__(MGX_LEXC_NT) void k_lex_chain(T *__restrict__ V, co
   // ---- the tile by its own hyperplanes i + j + k = m: lane = (j, k), every operand in LDS ----
   const bool mine = j < ny && k < nz;
   T *c0 = t + (k + 1) * PY + (j + 1) * PX + 1;
+  // A thread walks its row cell by cell, one cell every step from step j + k on.  Of a cell's seven operands only the
+  // new values at y - 1 and z - 1 (written by other threads one step earlier) have to be read after the step's barrier;
+  // the cell itself and its neighbours at x + 1, y + 1, z + 1 still hold old values (their owners get to them one or
+  // two steps later) and are read one step ahead, the new value at x - 1 is the thread's own last result.
+  T cur = (T)0, nxt = (T)0, yp = (T)0, zp = (T)0, prev = (T)0;
+  if (mine) { cur = c0[0]; nxt = c0[1]; yp = c0[PX]; zp = c0[PY]; prev = c0[-1]; }
   for (int m = 0; m < nx + ny + nz - 2; ++m) {
     const int i = m - j - k;
     if (mine && i >= 0 && i < nx) {
       T *c = c0 + i;
-      const T vc = c[0];
+      const T vc = cur, vxm = prev, vxp = nxt, vym = c[-PX], vyp = yp, vzm = c[-PY], vzp = zp;
       T vv = (T)0;
       bool have = false;
       if constexpr (BOXED) {
@@ -236,23 +242,28 @@ __global__ __launch_bounds__(MGX_LEXC_NT) void k_lex_chain(T *__restrict__ V, co
           for (int q = 1; q < TX / 4; ++q) word = (i >> 2) == q ? cw[q] : word;
           const unsigned code = (word >> ((i & 3) * 8)) & 255u;
           const T *w = &bl.wtab[0][0][0] + (code & 127u) * 6u;
-          T avg = c[-1] * w[0] + c[1] * w[1];
-          avg = avg + c[-PX] * w[2];
-          avg = avg + c[PX] * w[3];
-          avg = avg + c[-PY] * w[4];
-          avg = avg + c[PY] * w[5];
+          T avg = vxm * w[0] + vxp * w[1];
+          avg = avg + vym * w[2];
+          avg = avg + vyp * w[3];
+          avg = avg + vzm * w[4];
+          avg = avg + vzp * w[5];
           if ((code & 127u) == 64u)
-            avg = mgx_avg_general<T>(c[-1], c[1], c[-PX], c[PX], c[-PY], c[PY], sbx, nb, x0 + i, y0 + j, z0 + k + g.z0, p.a);
+            avg = mgx_avg_general<T>(vxm, vxp, vym, vyp, vzm, vzp, sbx, nb, x0 + i, y0 + j, z0 + k + g.z0, p.a);
           avg = (code & MGX_CODE_CONST) ? vc : avg;
           vv = p.s1 * vc + p.s2 * avg;
           have = true;
         }
       }
-      if (!have) vv = p.s1 * vc + p.s2 * mgx_avg_uniform<T>(c[-1], c[1], c[-PX], c[PX], c[-PY], c[PY], p.w);
+      if (!have) vv = p.s1 * vc + p.s2 * mgx_avg_uniform<T>(vxm, vxp, vym, vyp, vzm, vzp, p.w);
       const T dv = vv - vc;
       const T d2 = dv * dv;
       err = d2 > err ? d2 : err;
       c[0] = vv;
+      prev = vv;
+      cur = nxt;
+      nxt = c[2];                          // (up to the face towards x + 1; beyond the row's last cell: never used)
+      yp = c[PX + 1];
+      zp = c[PY + 1];
     }
     __syncthreads();
   }
