@@ -749,10 +749,10 @@ static int lex_sweep(mgx_level *lv, int reduce) {
     const int epoch = ++lv->lex_epoch;
     if (lv->nbox > 0)
       hipLaunchKernelGGL((k_lex_chain<T, true>), dim3((unsigned)nt), dim3(MGX_LEXC_NT), 0, st, (T *)lv->buf[lv->cur], g, p, lv->d_boxes,
-                         lv->nbox, lv->d_lex, lv->d_lex + nt, epoch, lv->lex_nt[0], lv->lex_nt[1], reduce & MGX_RED_ERR, lv->d_res);
+                         lv->nbox, lv->d_lex, lv->d_lex + nt, epoch, lv->lex_nt[0], lv->lex_nt[1], reduce & (MGX_RED_ERR | MGX_RED_SUM), lv->d_res);
     else
       hipLaunchKernelGGL((k_lex_chain<T, false>), dim3((unsigned)nt), dim3(MGX_LEXC_NT), 0, st, (T *)lv->buf[lv->cur], g, p, lv->d_boxes,
-                         lv->nbox, lv->d_lex, lv->d_lex + nt, epoch, lv->lex_nt[0], lv->lex_nt[1], reduce & MGX_RED_ERR, lv->d_res);
+                         lv->nbox, lv->d_lex, lv->d_lex + nt, epoch, lv->lex_nt[0], lv->lex_nt[1], reduce & (MGX_RED_ERR | MGX_RED_SUM), lv->d_res);
   } else
   if (mgx_lex_tiled) {      // a launch per tile hyperplane (k_lex_tile); MGX_LEX_TILED=0 selects the cell hyperplanes (k_lex_plane)
     const int ntx = (g.n1 + MGX_LEX_TX - 1) / MGX_LEX_TX, nty = (g.n2 + MGX_LEX_TY - 1) / MGX_LEX_TY,
@@ -769,7 +769,7 @@ static int lex_sweep(mgx_level *lv, int reduce) {
                          reduce & MGX_RED_ERR, lv->d_res);
   }
   HIP_TRY(hipGetLastError());
-  if (reduce & MGX_RED_SUM) {
+  if ((reduce & MGX_RED_SUM) && !chain) {       // (k_lex_chain sums its tiles itself, behind the hand-off to the next tile)
     const long long rows = (long long)g.n2 * g.n3;
     const int blocks = (int)std::max(1LL, std::min(4096LL, (rows + 3) / 4));
     hipLaunchKernelGGL((k_abs_sum<T>), dim3(blocks), dim3(256), 0, st, (const T *)lv->buf[lv->cur], g, 1, g.n3, lv->d_res);

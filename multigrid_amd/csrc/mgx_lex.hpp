@@ -320,5 +320,15 @@ __global__ __launch_bounds__(MGX_LEXC_NT) void k_lex_chain(T *__restrict__ V, co
     __hip_atomic_fetch_add(done + self, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     if (lost_) __hip_atomic_fetch_or(res + MGX_RES_ERRWORD, 1ull, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   }
-  if (reduce & 1) mgx_block_commit<NT / 64>((double)err, 0ull, 0ull, 0u, 1, res);
+  // the reductions, behind the hand-off (nobody waits for them): max dV^2 of the tile and, when asked for, the exact
+  // sum of |V| over the thread's row as the steps left it in LDS
+  u64 slo = 0, shi = 0;
+  unsigned ovf = 0;
+  if ((reduce & 2) && mine) {
+    for (int i = 0; i < nx; ++i) {
+      const T v = c0[i];
+      mgx_exact_add(slo, shi, (double)(v < (T)0 ? -v : v), ovf);
+    }
+  }
+  if (reduce & 3) mgx_block_commit<NT / 64>((double)err, slo, shi, ovf, reduce & 3, res);
 }
