@@ -1348,7 +1348,10 @@ static int launch_restrict(bool half, mgx_level *src, mgx_level *dst, const MgxT
   T *d = (T *)dst->buf[dst->cur];
   const int *mx = t->d_tab, *my = t->d_tab + t->off_y, *mz = t->d_tab + t->off_z;
   if (t->halved) {
-    constexpr int ZCH = 16;       // child planes one thread marches
+#ifndef MGX_RESTRICT_ZCH
+#define MGX_RESTRICT_ZCH 16
+#endif
+    constexpr int ZCH = MGX_RESTRICT_ZCH;       // child planes one thread marches
     dim3 g2((gd.n1 + 63) / 64, (gd.n2 + 3) / 4, (gd.n3 + ZCH - 1) / ZCH);
     if (half) hipLaunchKernelGGL((k_restrict_halved<T, true, ZCH>), g2, dim3(256), 0, st, s, src->g, d, gd);
     else hipLaunchKernelGGL((k_restrict_halved<T, false, ZCH>), g2, dim3(256), 0, st, s, src->g, d, gd);
@@ -1365,7 +1368,10 @@ template <typename T>
 static int launch_prolong(bool half, mgx_level *src, mgx_level *dst, const MgxTransferPlan *t) {
   const MgxGeom &gs = src->g;
   if (t->cz_hi < t->cz_lo) return MGX_OK;
-  constexpr int ZCH = 16;        // child planes one thread marches
+#ifndef MGX_PROLONG_ZCH
+#define MGX_PROLONG_ZCH 16
+#endif
+  constexpr int ZCH = MGX_PROLONG_ZCH;        // child planes one thread marches
   dim3 grid((gs.n1 + 63) / 64, (gs.n2 + 3) / 4, (t->cz_hi - t->cz_lo + ZCH) / ZCH);
   hipStream_t st = C(dst)->stream;
   const T *s = (const T *)src->buf[src->cur];
