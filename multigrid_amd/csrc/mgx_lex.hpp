@@ -27,6 +27,9 @@
 #ifndef MGX_LEXC_BATCH
 #define MGX_LEXC_BATCH 20                 /* loads a thread keeps in flight while it stages the tile's own cells */
 #endif
+#ifndef MGX_LEXC_AHEAD_TOP
+#define MGX_LEXC_AHEAD_TOP 1
+#endif
 #define MGX_LEXC_MAXSPIN (1 << 19)       /* polls before a tile gives up (each takes a microsecond or more) */
 
 template <typename T>
@@ -232,6 +235,11 @@ __global__ __launch_bounds__(MGX_LEXC_NT) void k_lex_chain(T *__restrict__ V, co
     if (mine && i >= 0 && i < nx) {
       T *c = c0 + i;
       const T vc = cur, vxm = prev, vxp = nxt, vym = c[-PX], vyp = yp, vzm = c[-PY], vzp = zp;
+      // 8-byte cells: the next step's old operands ride behind this step's two reads, so that the trip before the barrier
+      // is the store alone (4-byte cells measured slower that way: they read them behind the store)
+      constexpr bool AHEAD = MGX_LEXC_AHEAD_TOP && sizeof(T) == 8;
+      [[maybe_unused]] T n_nxt = (T)0, n_yp = (T)0, n_zp = (T)0;
+      if constexpr (AHEAD) { n_nxt = c[2]; n_yp = c[PX + 1]; n_zp = c[PY + 1]; }
       T vv = (T)0;
       bool have = false;
       if constexpr (BOXED) {
@@ -261,9 +269,13 @@ __global__ __launch_bounds__(MGX_LEXC_NT) void k_lex_chain(T *__restrict__ V, co
       c[0] = vv;
       prev = vv;
       cur = nxt;
-      nxt = c[2];                          // (up to the face towards x + 1; beyond the row's last cell: never used)
-      yp = c[PX + 1];
-      zp = c[PY + 1];
+      if constexpr (AHEAD) {
+        nxt = n_nxt; yp = n_yp; zp = n_zp;
+      } else {
+        nxt = c[2];                        // (up to the face towards x + 1; beyond the row's last cell: never used)
+        yp = c[PX + 1];
+        zp = c[PY + 1];
+      }
     }
     __syncthreads();
   }
